@@ -1,0 +1,179 @@
+"""Benchmark of the MARS alignment-and-ranking path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one query episode through the whole ranking path (the region the reference
+timestamps as ranking_time_after_text_extraction, /root/reference/mars/MARS.py:59-102) plus
+its IoU accounting.  Workload at every N: BASELINE.json configs[1] -- COCO-20i fold 0, 1-shot,
+DINOv2-L/14 reg4 @518, CLIP ViT-B/16, AlphaCLIP ViT-L/14@336, 64 proposals, bf16 towers --
+on seeded synthetic weights and episodes that are resident in HBM before the clock starts.
+Episodes shard round-robin over ranks (weak scaling: K episodes per GPU); the only collective
+is the sum of the [2, nclass] intersection/union buffers.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
+NPROP, SIZE, FOLD = 64, 518, 0
+
+
+def build_args(device, dtype):
+    return types.SimpleNamespace(
+        input_size=SIZE, num_regs=4, dino_backbone="vit_large", vta_backbone="ViT-B/16", alphaclip_backbone="ViT-L/14@336px",
+        vva_refinement_box_threshold=0.8, last_n_attn_for_vva_refinement=24, vta_refinement_box_threshold=0.4,
+        last_n_attn_for_vta_refinement=8, static_threshold=0.55, dynamic_threshold=0.95, alpha_coverage=0.85,
+        device=device, dtype=dtype, class_name="object", class_description="")
+
+
+def state_dicts(pkg, seed=0):
+    synth = pkg.synth
+    return dict(dino=synth.dinov2_state_dict(synth.dino_cfg("vit_large", SIZE), seed),
+                clip=synth.clip_state_dict(synth.CLIP_ARCHS["ViT-B/16"], seed),
+                alphaclip=synth.clip_state_dict(synth.CLIP_ARCHS["ViT-L/14@336px"], seed, alpha=True))
+
+
+def cpu_baseline(pkg, sds, sample_props=4):
+    """The CPU oracle on a bounded sample of the same workload: both DINOv2-L passes, the CLIP
+    pass with GradCAM and refinement, and `sample_props` of the 64 proposals through AlphaCLIP +
+    EMD; the per-proposal part is scaled to 64."""
+    from oracle import pipeline as opipe
+    synth = pkg.synth
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    d, c, a = synth.dino_cfg("vit_large", SIZE), synth.CLIP_ARCHS["ViT-B/16"], synth.CLIP_ARCHS["ViT-L/14@336px"]
+    models = dict(
+        dino_sd=sds["dino"], dino_kw=dict(depth=d.depth, heads=d.num_heads, patch=14, num_regs=4, ffn="mlp"),
+        clip_sd=sds["clip"], clip_kw=dict(layers=c.vision_layers, heads=c.vision_heads, patch=16, text_layers=c.transformer_layers,
+                                          text_heads=c.transformer_heads),
+        aclip_sd=sds["alphaclip"], aclip_kw=dict(layers=a.vision_layers, heads=a.vision_heads, patch=14, resolution=336,
+                                                 text_layers=a.transformer_layers, text_heads=a.transformer_heads))
+    ep = synth.make_episode(1000 * FOLD, size=SIZE, nshot=1, nprop=NPROP, fold=FOLD)
+    tok = dict(fg=synth.tokenize(["a photo of object."]), bg=synth.tokenize(["a photo without object."]),
+               alphaclip=synth.tokenize(["a object."]))
+    with torch.no_grad():
+        t0 = time.time()
+        v = opipe.vva_compute(models["dino_sd"], models["dino_kw"], ep["support_imgs"], ep["support_masks"], ep["query_img"])
+        t1 = time.time()
+    t = opipe.vta_compute(models["clip_sd"], models["clip_kw"], ep["query_img"], tok["fg"], tok["bg"])
+    t2 = time.time()
+    g = v["vva"].shape[0]
+    vta = torch.nn.functional.interpolate(t["vta"][None, None], (g, g), mode="nearest")[0, 0]
+    with torch.no_grad():
+        opipe.fmm_scores(models["aclip_sd"], models["aclip_kw"], ep["query_img"], ep["mask_proposals"][:sample_props],
+                         ep["support_masks"], v["cost"], g, v["vva"], opipe.minmax(vta), tok["alphaclip"], batch=sample_props)
+    t3 = time.time()
+    per_query = (t1 - t0) + (t2 - t1) + (t3 - t2) * (NPROP / sample_props)
+    return {"value": 1.0 / per_query, "unit": "query images/s", "cores": cores, "kind": "port",
+            "sample": f"1 episode of the same workload: DINOv2-L x2 {t1 - t0:.1f}s + CLIP-B/16 GradCAM {t2 - t1:.1f}s measured in "
+                      f"full, {sample_props} of {NPROP} proposals through AlphaCLIP-L/14@336 + exact EMD {t3 - t2:.1f}s scaled x"
+                      f"{NPROP // sample_props}; fp32 torch CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = load_package(require_native=True)
+    from importlib import import_module
+    MARS = import_module(pkg.__name__ + ".mars.MARS")
+    Evaluator = import_module(pkg.__name__ + ".mars.utils.evaluation").Evaluator
+    AverageMeter = import_module(pkg.__name__ + ".mars.utils.logger").AverageMeter
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    sds = state_dicts(pkg)
+    mars = MARS.build_MARS_fss(build_args(dev, dtype), state_dicts=sds)
+    Evaluator.initialize()
+    dataset = types.SimpleNamespace(benchmark="coco", class_ids=[FOLD + 4 * i for i in range(20)])
+    meter = AverageMeter(dataset, device=dev)
+
+    # this rank's episodes: global index e = k * world + rank, seed = 1000*fold + e, resident in HBM
+    total = args.steps + args.warmup
+    eps = []
+    for k in range(total):
+        e = k * world + rank
+        ep = pkg.synth.make_episode(1000 * FOLD + e, size=SIZE, nshot=1, nprop=NPROP, fold=FOLD)
+        eps.append({k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in ep.items()})
+
+    def step(ep, count=True):
+        pred = mars.predict(ep["support_imgs"], ep["support_masks"], ep["query_img"], ep["mask_proposals"])
+        ai, au = Evaluator.classify_prediction(pred[None], ep)
+        if count:
+            meter.update(ai, au, ep["class_id"])
+        mars.clear()
+
+    for k in range(args.warmup):
+        step(eps[k], count=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    pkg.ops.GEMM_PROFILE = []
+    pkg.ops.GEMM_PROFILE_DTYPE = 1 if args.dtype == "bf16" else 0
+    t0 = time.perf_counter()
+    for k in range(args.warmup, total):
+        step(eps[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof, pkg.ops.GEMM_PROFILE = pkg.ops.GEMM_PROFILE, None
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        meter.all_reduce()
+    elapsed = float(el)
+    miou, fb_iou, _ = meter.compute_iou()
+
+    if rank == 0:
+        # dominant kernel: the bf16 (or f32) MFMA GEMM, timed per launch with events on its stream
+        flops = sum(p[2] for p in prof)
+        ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        out = {
+            "metric": "query images/sec", "value": args.steps * world / elapsed, "unit": "query images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "COCO-20i fold0 1-shot, DINOv2-L/14-reg4@518 + CLIP ViT-B/16 GradCAM + AlphaCLIP ViT-L/14@336, "
+                                   "64 proposals, exact EMD, rank+merge+IoU (BASELINE configs[1])",
+                       "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}"},
+            "miou": float(miou), "fb_iou": float(fb_iou),
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "kernel": "gemm_tn_kernel", "launches": len(prof),
+                         "avg_launch_us": ms * 1e3 / max(len(prof), 1), "gemm_share_of_step": ms / (elapsed * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, sds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

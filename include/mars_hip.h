@@ -1,0 +1,203 @@
+/* C-ABI of libmars_hip.so: the MI355X (gfx950) kernels beneath the MARS
+ * alignment-and-ranking path.
+ *
+ * The reference (a pure Python / PyTorch pipeline) has no FFI of its own; its seam is
+ * the Python object API (mars.MARS.MARS, the four components, BackboneLoader).  Each
+ * entry point below names the reference lines whose arithmetic it replaces.  The
+ * Python shells in the package keep the reference signatures and call these through
+ * ctypes with tensor.data_ptr() values.
+ *
+ * Conventions
+ *   - every device buffer is allocated by the caller; the library owns no device memory
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), no sync
+ *   - return 0 on success, negative on error; marship_last_error() gives the text
+ *   - "TN GEMM": C[M,N] = A[M,K] * B[N,K]^T, both operands K-contiguous
+ *   - dtype codes: 0 = float32, 1 = bfloat16
+ */
+#ifndef MARS_HIP_H
+#define MARS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* marship_last_error(void);
+int marship_version(void);
+
+/* ---- dense contractions ------------------------------------------------------- */
+typedef struct MarsGemm {
+    const void* A; const void* B; void* C;
+    int64_t lda, ldb, ldc;           /* in elements */
+    int64_t sA0, sA1, sB0, sB1, sC0, sC1; /* batch strides (elements): outer, inner */
+    int32_t M, N, K;                 /* K*elemsize must be a multiple of 128 bytes */
+    int32_t nb0, nb1;                /* batch = nb0*nb1; outer index = z / nb1 */
+    const float* bias;               /* [N] or NULL */
+    const float* gamma;              /* [N] or NULL (LayerScale) */
+    const float* residual;           /* f32 [M,N] or NULL, added last */
+    int64_t ldr, sR0, sR1;
+    float alpha;                     /* applied to the accumulator first */
+    int32_t act;                     /* 0 none, 1 GELU(erf), 2 QuickGELU */
+    int32_t in_dtype;                /* A and B: 0 f32, 1 bf16 */
+    int32_t out_dtype;               /* C: 0 f32, 1 bf16 */
+} MarsGemm;
+/* Every nn.Linear / conv-as-GEMM / similarity / refinement product on the path:
+ * dinov2/layers/attention.py:51,61; mlp.py:35-41; patch_embed.py:76; clip/model.py:283-300,361;
+ * alpha_clip/model.py:222,251,359-361; VisualVisualAlignmentModule.py:69,78-79;
+ * PriorInformationRefinementModule.py:74-79. out = residual + gamma*act(alpha*A.B^T + bias). */
+int marship_gemm(const MarsGemm* g, void* stream);
+
+/* ---- ViT glue ------------------------------------------------------------------ */
+/* nn.LayerNorm over the last dim (dinov2 vision_transformer.py:97 eps 1e-6; clip/model.py:265-271
+ * eps 1e-5, computed in f32).  x f32 [rows, D] with row stride x_stride; y out_dtype. */
+int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
+                      int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream);
+/* Patch extraction for the strided conv patch embeddings (patch_embed.py:76; clip/model.py:361;
+ * alpha_clip/model.py:359-361) with the input normalisation (x*prescale - mean[c])/std[c] fused
+ * (backbone_loader.py:74-78,178-179,185).  img [B,C,H,W] (f32, or u8 when in_u8), out
+ * [B*gh*gw, ldo] with column c*p*p+dy*p+dx+col_off; columns >= C*p*p+col_off up to ldo are not
+ * touched. */
+int marship_im2col(const void* img, int in_u8, int B, int C, int H, int W, int p, const float* mean,
+                   const float* stdv, float prescale, void* out, int64_t ldo, int col_off,
+                   int out_dtype, void* stream);
+/* Token rows that do not come from the patch GEMM: cls(+pos[0]) and register tokens
+ * (vision_transformer.py:230-241; clip/model.py:364-365). X f32 [B,T,D]. */
+int marship_write_prefix_tokens(float* X, int B, int T, int D, const float* cls, const float* pos0,
+                                const float* regs, int num_regs, void* stream);
+/* Batched transpose of 2-byte or 4-byte elements: out[b][c][r] = in[b][r][c]. */
+int marship_transpose(const void* in, int64_t ldi, int64_t sI0, int64_t sI1, void* out, int64_t ldo,
+                      int64_t sO0, int64_t sO1, int rows, int cols, int nb0, int nb1, int elem_size,
+                      void* stream);
+/* Row softmax of attention scores (attention.py:57; alpha_clip/model.py:243; causal mask of
+ * clip/model.py:471-477).  S f32 [nb, T, lds]; P out_dtype [nb, T, ldp], columns T..ldp-1 zeroed. */
+int marship_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int nb, int T, int causal,
+                         int out_dtype, void* stream);
+/* acc[i,j] += scale * sum_h P[h, off+i, off+j]  (PriorInformationRefinementModule.py:31-45 and
+ * nn.MultiheadAttention's head averaging, clip/model.py:295). P in_dtype [H, T, ldp]. */
+int marship_attn_mean_accum(const void* P, int64_t ldp, int64_t head_stride, int H, int off, int Pn,
+                            float scale, float* acc, int64_t ldacc, int in_dtype, void* stream);
+/* SwiGLU gate: out[m*ldo + j] = silu(x[m, j]) * x[m, Hd + j]  (swiglu_ffn.py:29-33). */
+int marship_swiglu(const void* x12, void* out, int64_t ldo, int M, int Hd, int dtype, void* stream);
+/* dtype casts between f32 and bf16 over n contiguous elements. */
+int marship_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
+
+/* Fused attention for 64-wide heads on packed qkv [B*T, 3*D] (bf16):
+ * O = softmax(q*scale k^T) v  (attention.py:54-60; alpha_clip/model.py:233-246), O bf16 [B*T, D];
+ * lse f32 [B*H, T] receives log-sum-exp of the scaled scores (may be NULL). */
+int marship_flash_attn(const void* qkv, void* O, float* lse, int B, int T, int H, int causal,
+                       void* stream);
+/* acc[i,j] += scale * sum_h exp(q_h[i].k_h[j]/8 - lse[h,i]) over the patch block starting at
+ * token `off` of image 0 (bf16 qkv as above): the head/layer mean of the attention maps
+ * (PriorInformationRefinementModule.py:31-45) without materialising them. */
+int marship_flash_attn_mean(const void* qkv, const float* lse, int T, int H, int off, int Pn,
+                            float scale, float* acc, int64_t ldacc, void* stream);
+
+/* ---- alignment / refinement ------------------------------------------------------ */
+/* F.normalize(p=2, dim=1) on gathered rows (VisualVisualAlignmentModule.py:122-125;
+ * FilteringMergingModule.py:179,200).  Row r of image b is x + b*x_bstride + (row_off+r)*x_stride. */
+int marship_l2norm_rows(const float* x, int64_t x_bstride, int64_t x_stride, int row_off, int B,
+                        int rows, int D, void* y, int64_t y_stride, int out_dtype, void* stream);
+/* Foreground/background column statistics of S and the raw prior
+ * vva = mean_fg*max_fg - mean_bg*max_bg, min-max scaled (VisualVisualAlignmentModule.py:76-102).
+ * S f32 [R, ldS] (R = ns*P), fg u8 [R]; ws f32 workspace of 4*chunks*P floats; out f32 [P]. */
+int marship_vva_prior(const float* S, int64_t ldS, const uint8_t* fg, int R, int P, float* ws,
+                      int chunks, float* out, void* stream);
+/* (x - min) / (1e-7 + max - min) over n elements (single block). */
+int marship_minmax(const float* x, float* y, int n, void* stream);
+/* Box mask B of the thresholded prior (PriorInformationRefinementModule.py:53-65,91-122):
+ * u8 = trunc(prior*255); keep u8 > int(thr*max(u8)); bounding box of every 8-connected component,
+ * x1=min(x+w,W-1), y1=min(y+h,H-1); fill [y0:y1, x0:x1].  prior f32 [G,G], Bm f32 [G*G]. */
+int marship_box_mask(const float* prior, int G, double threshold, float* Bm, void* stream);
+/* D = A / colsum(A); D = D / rowsum(D)  (PriorInformationRefinementModule.py:70-71).
+ * A f32 [P, ldA]; D f32 [P, ldD] with columns P..ldD-1 zeroed; colsum: f32 scratch of 33*P. */
+int marship_sinkhorn1(const float* A, int64_t ldA, float* D, int64_t ldD, int P, float* colsum,
+                      void* stream);
+/* R = max(D, DDT) written both as R [P, ld] and R^T [P, ld], pads zeroed (line 74-75). */
+int marship_max_and_transpose(const float* D, const float* DDT, int64_t ld, int P, float* R,
+                              float* RT, void* stream);
+/* out[i] = sum_j R2[i,j] * Bm[j] * prior[j]  (lines 81-87). */
+int marship_masked_matvec(const float* R2, int64_t ld, const float* Bm, const float* prior, int P,
+                          float* out, void* stream);
+
+/* ---- resampling ------------------------------------------------------------------ */
+/* Separable weighted resample with host-built tables (torch antialiased bicubic / bilinear:
+ * VisualTextAlignmentModule.py:88-92; backbone_loader.py:182-186).  One pass along `axis`
+ * (1 = width, 0 = height) of in [planes, H, W]: out[.., o, ..] = sum_k w[o,k] * in[.., xmin[o]+k, ..]
+ * with `nout` output positions on that axis.  `quant_u8` applies v = trunc(v*255)/255 to the
+ * input first (FilteringMergingModule.py:194); the result is (acc - shift)/scale.  Two calls
+ * (width, then height) resample an image. */
+int marship_resample_axis(const float* in, int planes, int H, int W, int axis, int nout,
+                          const int32_t* xmin, const int32_t* xsize, const float* weights, int kmax,
+                          int quant_u8, float shift, float scale, void* out, int out_dtype,
+                          void* stream);
+/* PIL (Pillow) 8-bit resample pass with 22-bit fixed-point coefficients
+ * (backbone_loader.py:172-176 via PIL.Image.resize): out = clip8((2^21 + sum in*kk) >> 22). */
+int marship_resample_axis_u8(const uint8_t* in, int planes, int H, int W, int axis, int nout,
+                             const int32_t* xmin, const int32_t* xsize, const int32_t* kk, int kmax,
+                             uint8_t* out, void* stream);
+/* img f32 [C,H,W] in [0,1] -> u8 trunc(x*255) (torchvision ToPILImage on a float array). */
+int marship_f32_to_u8(const float* in, uint8_t* out, int64_t n, void* stream);
+
+/* ---- proposal pooling / scoring / merge / IoU ----------------------------------- */
+/* adaptive_max_pool2d(mask, G) > 0 (FilteringMergingModule.py:73-81,104-107;
+ * VisualVisualAlignmentModule.py:72-75). masks f32 [N,S,S] -> bits u8 [N, G*G]. */
+int marship_pool_masks(const float* masks, int N, int S, int G, uint8_t* bits, void* stream);
+/* Per-proposal patch statistics (FilteringMergingModule.py:108-110): cnt[n] = |m_n|,
+ * sum_vva[n], sum_vta[n]; union_cnt = |OR_n m_n|. */
+int marship_proposal_stats(const uint8_t* bits, int N, int P, const float* vva, const float* vta,
+                           int32_t* cnt, float* sum_vva, float* sum_vta, int32_t* union_cnt,
+                           void* stream);
+/* AlphaCLIP score: s[n] = <f_n/|f_n|, t/|t|> (FilteringMergingModule.py:97,179,200). */
+int marship_cosine_scores(const float* feats, int64_t ldf, int N, int E, const float* text,
+                          float* scores, void* stream);
+/* Scores, ranking and keep decision in float64 (FilteringMergingModule.py:118-138,213-217):
+ * order[k] = index of the k-th best proposal (stable), keep[n] in {0,1}. */
+int marship_rank(const double* emd, const float* aclip, const int32_t* cnt, const float* sum_vva,
+                 const float* sum_vta, const int32_t* union_cnt, int N, double alpha,
+                 double static_thr, double dynamic_thr, double* score, int32_t* order,
+                 uint8_t* keep, void* stream);
+/* merged = (sum of kept masks > 0) (FilteringMergingModule.py:219). */
+int marship_merge_masks(const float* masks, const uint8_t* keep, int N, int64_t HW, float* merged,
+                        void* stream);
+/* Intersection / union areas (mars/utils/evaluation.py:11-39): counts[0..3] += {inter0, inter1,
+ * union0, union1} over pixels whose ignore flag is 0. */
+int marship_iou_counts(const float* pred, const float* gt, const float* ignore, int64_t HW,
+                       float* counts, void* stream);
+
+/* ---- GradCAM backward pieces ----------------------------------------------------- */
+/* LayerNorm backward w.r.t. the input: dx = add + LN'(x)[dy*w].  dy row r is dy + r*dy_stride
+ * (dy_stride 0 broadcasts one row); rows < skip_rows get dy = 0. */
+int marship_layernorm_bwd(const float* x, const float* w, const float* dy, int64_t dy_stride,
+                          float dy_scale, int skip_rows, const float* add, float* dx, int rows, int D,
+                          float eps, void* stream);
+/* d/dz [z*sigmoid(1.702 z)] applied to dh (clip/model.py:274-276). */
+int marship_quickgelu_bwd(const float* dh, const float* pre, float* out, int64_t n, void* stream);
+/* dS = P * (dP - rowsum(dP*P)) * scale, per row (softmax backward). */
+int marship_softmax_bwd(const float* P, const float* dP, float* dS, int64_t ld, int nb, int T,
+                        float scale, void* stream);
+/* out[c] = mean over rows r0..r1-1 of x[r, c]. */
+int marship_col_mean(const float* x, int64_t ld, int r0, int r1, int D, float* out, void* stream);
+/* Head of forward_last_layer and its gradient (clip/model.py:506-521): from f = mean patch token
+ * of ln_post, logits = softmax(exp(logit_scale) * norm(f@proj) . norm(text)^T); df = d logits[0]/df.
+ * proj f32 [D,E], text f32 [2,E]. */
+int marship_cam_head(const float* f, const float* proj, const float* text, int D, int E,
+                     float logit_scale_exp, float* logits, float* df, void* stream);
+/* cam[t] = relu(sum_c w[c]*act[t,c]) for rows r0.. (grad_cam.py:16-23; base_cam.py:55-60,154). */
+int marship_cam_rows(const float* act, int64_t ld, const float* w, int r0, int rows, int D, float* cam,
+                     void* stream);
+
+/* ---- host routines --------------------------------------------------------------- */
+/* Exact EMD scores 1 - emd2(1/n, 1/m, C[fg rows][:, mask cols]) with C = (1-S)/2
+ * (FilteringMergingModule.py:142-169; matcher/Matcher.py:1188-1193; POT 0.9.4 ot.emd2).
+ * S host f32 [R, ldS] (the similarity matrix, or the cost matrix itself when is_cost != 0);
+ * fg u8 [R]; bits u8 [N, P]; out f64 [N].  Network simplex, one problem per worker thread. */
+int marshost_emd_scores(const float* S, int64_t ldS, int R, int P, const uint8_t* fg,
+                        const uint8_t* bits, int N, int is_cost, double* out, int threads);
+/* Same solver on an explicit cost matrix (f64 [n, m]). */
+double marshost_emd2_uniform(const double* C, int n, int m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARS_HIP_H */

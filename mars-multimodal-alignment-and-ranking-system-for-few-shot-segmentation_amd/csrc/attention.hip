@@ -1,0 +1,243 @@
+// Fused attention for 64-wide heads (bf16 in, f32 accumulate) and the fused
+// head/layer mean of the attention probabilities.
+//
+// Orientation: each wave owns 16 queries and computes S^T = K * Q^T with
+// v_mfma_f32_16x16x32_bf16, so a query is a LANE column (query = lane & 15) and its
+// 64 keys of a tile sit in 16 accumulator registers spread over the four 16-lane
+// groups.  The online-softmax statistics are then per-lane scalars (two xor
+// shuffles finish a row), and the probabilities are already the B operand of
+// O^T += V^T * P^T: registers of fragment pair (2s, 2s+1) give the eight k slots of
+// k-step s, i.e. keys 32s + 4g + {0..3} and 32s + 16 + 4g + {0..3} for lane group g.
+// The A operand V^T[d][those keys] comes straight from the row-major V tile in LDS
+// through ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group, delivered column-wise).
+#include "common.h"
+#include "../../include/mars_hip.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int KT = 64;           // keys per tile
+constexpr int ROWB = 128;        // bytes per LDS row (64 bf16)
+
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 a, f32x4 b) {
+    bf16x8 r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    return r;
+}
+
+// V^T fragment for d-block m and k-step s from the row-major [key][d] tile
+__device__ __forceinline__ bf16x8 load_vt_frag(const unsigned char* vt, int lane, int m, int s) {
+    const int g = lane >> 4, ii = lane & 15;
+    const int q = ii >> 2, p = ii & 3;
+    const int colb = 32 * m + 8 * p;  // byte offset of d = 16m + 4p inside the row
+    const int r0 = 32 * s + 4 * g + q, r1 = r0 + 16;
+    const int a0 = tile_off(r0, colb >> 4) + (colb & 15);
+    const int a1 = tile_off(r1, colb >> 4) + (colb & 15);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vt + a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vt + a1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256) void flash_attn_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ O,
+                                                         float* __restrict__ lse, int T, int H, int causal) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KT * ROWB];  // [buf][K|V]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int D = H * 64;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int64_t row_b = (int64_t)3 * D * 2;  // bytes per token row of qkv
+    const unsigned char* base = (const unsigned char*)qkv + (int64_t)b * T * row_b + (int64_t)h * 128;
+
+    // Q^T operand: lane = query r16, d = 8g + j (+32 for the second k-step)
+    const int qrow = min(q0 + r16, T - 1);
+    const unsigned char* qp = base + (int64_t)qrow * row_b;
+    const bf16x8 qf0 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 16 * g));
+    const bf16x8 qf1 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 + 16 * g));
+
+    // staging: 512 chunks per tile and operand, 2 per thread
+    const unsigned char* kp[2]; const unsigned char* vp[2]; int dst[2]; int srow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int qd = tid + 256 * i;
+        srow[i] = qd >> 3;
+        const int c = qd & 7;
+        kp[i] = base + (int64_t)D * 2 + c * 16;
+        vp[i] = base + (int64_t)D * 4 + c * 16;
+        dst[i] = tile_off(srow[i], c);
+    }
+    const int nt = (T + KT - 1) / KT;
+    uint4 rk[2], rv[2];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(t * KT + srow[i], T - 1);
+            rk[i] = *(const uint4*)(kp[i] + (int64_t)key * row_b);
+            rv[i] = *(const uint4*)(vp[i] + (int64_t)key * row_b);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { *(uint4*)(&lds[buf][0][dst[i]]) = rk[i]; *(uint4*)(&lds[buf][1][dst[i]]) = rv[i]; }
+    };
+
+    f32x4 o[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) o[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;
+    const float scale = 0.125f;
+    const int myq = q0 + r16;
+
+    // causal: tiles past the last query of this block are never needed
+    const int nt_eff = causal ? min(nt, (blockIdx.x * 64 + 63) / KT + 1) : nt;
+    gload(0); swrite(0);
+    __syncthreads();
+    for (int t = 0; t < nt_eff; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt_eff) gload(t + 1);
+        const unsigned char* kt_ = &lds[buf][0][0];
+        const unsigned char* vt_ = &lds[buf][1][0];
+        f32x4 s[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, g)));
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, 4 + g)));
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, acc, 0, 0, 0);
+            s[f] = acc;
+        }
+        // mask + running max (lane holds keys t*64 + 16f + 4g + j for query r16)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = t * KT + 16 * f + 4 * g + j;
+                float v = s[f][j] * scale;
+                if (key >= T || (causal && key > myq)) v = -INFINITY;
+                s[f][j] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = (mnew == -INFINITY) ? 1.f : expf(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p = (mnew == -INFINITY) ? 0.f : expf(s[f][j] - mnew);
+                s[f][j] = p;
+                ps += p;
+            }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { o[m][0] *= alpha; o[m][1] *= alpha; o[m][2] *= alpha; o[m][3] *= alpha; }
+        const bf16x8 p0 = pack_bf16x8(s[0], s[1]);
+        const bf16x8 p1 = pack_bf16x8(s[2], s[3]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            o[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag(vt_, lane, m, 0), p0, o[m], 0, 0, 0);
+            o[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag(vt_, lane, m, 1), p1, o[m], 0, 0, 0);
+        }
+        if (t + 1 < nt_eff) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    if (myq < T) {
+        const float inv = 1.0f / lrun;
+        __bf16* op = O + ((int64_t)b * T + myq) * D + h * 64;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            bf16x4 v;
+            v[0] = (__bf16)(o[m][0] * inv); v[1] = (__bf16)(o[m][1] * inv);
+            v[2] = (__bf16)(o[m][2] * inv); v[3] = (__bf16)(o[m][3] * inv);
+            *(bf16x4*)(op + 16 * m + 4 * g) = v;
+        }
+        if (lse && g == 0) lse[(int64_t)bh * T + myq] = mrun + logf(lrun);
+    }
+}
+
+// acc[i][j] += scale_out * sum_h exp(q_h[off+i].k_h[off+j]/8 - lse[h][off+i])
+__global__ __launch_bounds__(256) void flash_attn_mean_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ lse,
+                                                              int T, int H, int off, int Pn, float scale_out,
+                                                              float* __restrict__ acc_out, int64_t ldacc) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[KT * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int D = H * 64;
+    const int64_t row_b = (int64_t)3 * D * 2;
+    const int i0 = blockIdx.y * 64 + wave * 16, j0 = blockIdx.x * 64;
+    const int myi = i0 + r16;
+    const int qrow = off + min(myi, Pn - 1);
+    const unsigned char* base = (const unsigned char*)qkv;
+    f32x4 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < H; ++h) {
+        const unsigned char* hb = base + (int64_t)h * 128;
+        const unsigned char* qp = hb + (int64_t)qrow * row_b;
+        const bf16x8 qf0 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 16 * g));
+        const bf16x8 qf1 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 + 16 * g));
+        const float l = lse[(int64_t)h * T + qrow];
+        __syncthreads();  // previous head's reads of the K tile are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = tid + 256 * i, r = qd >> 3, c = qd & 7;
+            const int key = off + min(j0 + r, Pn - 1);
+            *(uint4*)(&lds[tile_off(r, c)]) = *(const uint4*)(hb + (int64_t)D * 2 + (int64_t)key * row_b + c * 16);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *(const uint4*)(lds + tile_off(16 * f + r16, g)));
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *(const uint4*)(lds + tile_off(16 * f + r16, 4 + g)));
+            f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][j] += expf(s[j] * 0.125f - l);
+        }
+    }
+    if (myi < Pn) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = j0 + 16 * f + 4 * g + j;
+                if (col < Pn) acc_out[(int64_t)myi * ldacc + col] += scale_out * acc[f][j];
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int marship_flash_attn(const void* qkv, void* O, float* lse, int B, int T, int H, int causal, void* stream) {
+    MARS_CHECK(qkv && O, "flash_attn: null pointer");
+    MARS_CHECK(B > 0 && T > 0 && H > 0 && (int64_t)B * H <= 65535, "flash_attn: bad shape B=%d T=%d H=%d", B, T, H);
+    MARS_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)O % 8) == 0, "flash_attn: misaligned buffers");
+    dim3 grid((T + 63) / 64, B * H), block(256);
+    hipLaunchKernelGGL(flash_attn_kernel, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, causal);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_flash_attn_mean(const void* qkv, const float* lse, int T, int H, int off, int Pn, float scale,
+                                       float* acc, int64_t ldacc, void* stream) {
+    MARS_CHECK(qkv && lse && acc, "flash_attn_mean: null pointer");
+    MARS_CHECK(T > 0 && H > 0 && off >= 0 && Pn > 0 && off + Pn <= T && ldacc >= Pn, "flash_attn_mean: bad shape");
+    MARS_CHECK(((uintptr_t)qkv % 16) == 0, "flash_attn_mean: misaligned qkv");
+    dim3 grid((Pn + 63) / 64, (Pn + 63) / 64), block(256);
+    hipLaunchKernelGGL(flash_attn_mean_kernel, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, lse, T, H, off, Pn, scale, acc, ldacc);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,184 @@
+// TN GEMM on the gfx950 matrix cores: C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue
+//   out = residual + gamma[n] * act(alpha * acc + bias[n]).
+//
+// One kernel body serves both input types because the LDS image is defined in BYTES:
+// a k-tile is 128 bytes per row (64 bf16 or 32 f32), cut into eight 16-byte chunks.
+// Lane l of a wave owns row (l & 15) of a 16-row fragment and chunk (l >> 4) of each
+// 64-byte half.  For bf16 that chunk is exactly the 8-element A/B operand of
+// v_mfma_f32_16x16x32_bf16.  For f32 the four floats of the chunk feed four
+// v_mfma_f32_16x16x4_f32: MFMA s takes float s of every lane, i.e. k = 4*(l>>4)+s --
+// a permutation of k inside the 16-float block that A and B share, so the sum is
+// unchanged.  Both MFMAs have the same C/D map (col = l & 15, row = 4*(l>>4)+reg).
+//
+// Tile 128x128, 4 waves as 2x2, each wave 64x64 = 4x4 fragments.  Global -> register ->
+// LDS staging with the next tile's loads in flight during the MFMAs, two LDS buffers,
+// one barrier per k-tile.  Chunk c of row r is stored at chunk c ^ ((r >> 1) & 7) so the
+// 16 rows a ds_read_b128 lane group touches land on 16 distinct 16-byte bank slots.
+// Out-of-range rows are clamped on the source address (results never stored).
+#include "common.h"
+#include "../../include/mars_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BKB = 128;  // BKB: bytes of K per tile row
+constexpr int THREADS = 256;
+
+struct Epi {
+    const float* bias; const float* gamma; const float* residual;
+    int64_t ldr; float alpha; int act;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 2) return v / (1.0f + expf(-1.702f * v));
+    return v;
+}
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * BKB + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(THREADS) void gemm_tn_kernel(MarsGemm g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * BKB];  // [buf][A|B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // XCD-aware tile order: blocks that share an L2 (same blockIdx % 8) walk a contiguous tile range
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int z = blockIdx.y, z0 = z / g.nb1, z1 = z % g.nb1;
+
+    const unsigned char* Ab = (const unsigned char*)g.A + (z0 * g.sA0 + z1 * g.sA1) * (int64_t)sizeof(TIN);
+    const unsigned char* Bb = (const unsigned char*)g.B + (z0 * g.sB0 + z1 * g.sB1) * (int64_t)sizeof(TIN);
+    const int64_t lda_b = g.lda * (int64_t)sizeof(TIN), ldb_b = g.ldb * (int64_t)sizeof(TIN);
+
+    // staging assignment: 1024 chunks per operand tile, 4 per thread
+    const unsigned char* pa[4];
+    const unsigned char* pb[4];
+    int dst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + THREADS * i, r = q >> 3, c = q & 7;
+        int ra = row0 + r; ra = ra < g.M ? ra : g.M - 1;
+        int rb = col0 + r; rb = rb < g.N ? rb : g.N - 1;
+        pa[i] = Ab + ra * lda_b + c * 16;
+        pb[i] = Bb + rb * ldb_b + c * 16;
+        dst[i] = lds_off(r, c);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(((int64_t)g.K * sizeof(TIN)) / BKB);
+    uint4 ra4[4], rb4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ra4[i] = *(const uint4*)(pa[i]); rb4[i] = *(const uint4*)(pb[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { *(uint4*)(&lds[0][0][dst[i]]) = ra4[i]; *(uint4*)(&lds[0][1][dst[i]]) = rb4[i]; }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            const int64_t ko = (int64_t)(kt + 1) * BKB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra4[i] = *(const uint4*)(pa[i] + ko); rb4[i] = *(const uint4*)(pb[i] + ko); }
+        }
+        const unsigned char* la = &lds[buf][0][0];
+        const unsigned char* lb = &lds[buf][1][0];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            uint4 fa[4], fb[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(la + lds_off(wr * 64 + m * 16 + r16, kc * 4 + kq));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) fb[n] = *(const uint4*)(lb + lds_off(wc * 64 + n * 16 + r16, kc * 4 + kq));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if constexpr (sizeof(TIN) == 2) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[m]), __builtin_bit_cast(bf16x8, fb[n]), acc[m][n], 0, 0, 0);
+                    } else {
+                        const f32x4 a = __builtin_bit_cast(f32x4, fa[m]);
+                        const f32x4 b = __builtin_bit_cast(f32x4, fb[n]);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[m][n], 0, 0, 0);
+                    }
+                }
+        }
+        if (kt + 1 < nk) {
+            const int nb = buf ^ 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { *(uint4*)(&lds[nb][0][dst[i]]) = ra4[i]; *(uint4*)(&lds[nb][1][dst[i]]) = rb4[i]; }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows 4*kq + j (j = 0..3) and column r16 of each 16x16 fragment
+    TOUT* Cb = (TOUT*)g.C + (z0 * g.sC0 + z1 * g.sC1);
+    const float* Rb = g.residual ? g.residual + (z0 * g.sR0 + z1 * g.sR1) : nullptr;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int col = col0 + wc * 64 + n * 16 + r16;
+        if (col >= g.N) continue;
+        const float bias = g.bias ? g.bias[col] : 0.f;
+        const float gam = g.gamma ? g.gamma[col] : 1.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + wr * 64 + m * 16 + kq * 4 + j;
+                if (row >= g.M) continue;
+                float v = apply_act(g.alpha * acc[m][n][j] + bias, g.act) * gam;
+                if (Rb) v += Rb[(int64_t)row * g.ldr + col];
+                st_from_f32<TOUT>(Cb + (int64_t)row * g.ldc + col, v);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
+    MARS_CHECK(g && g->A && g->B && g->C, "gemm: null operand");
+    MARS_CHECK(g->M > 0 && g->N > 0 && g->K > 0 && g->nb0 > 0 && g->nb1 > 0, "gemm: bad shape M=%d N=%d K=%d", g->M, g->N, g->K);
+    const int es = g->in_dtype == 1 ? 2 : 4;
+    MARS_CHECK(g->in_dtype == 0 || g->in_dtype == 1, "gemm: in_dtype %d", g->in_dtype);
+    MARS_CHECK(g->out_dtype == 0 || g->out_dtype == 1, "gemm: out_dtype %d", g->out_dtype);
+    MARS_CHECK(((int64_t)g->K * es) % BKB == 0, "gemm: K=%d must span a multiple of 128 bytes (pad with zeros)", g->K);
+    MARS_CHECK((g->lda * es) % 16 == 0 && (g->ldb * es) % 16 == 0, "gemm: lda/ldb rows must be 16-byte multiples");
+    MARS_CHECK(((uintptr_t)g->A % 16) == 0 && ((uintptr_t)g->B % 16) == 0, "gemm: A/B must be 16-byte aligned");
+    MARS_CHECK((g->sA0 * es) % 16 == 0 && (g->sA1 * es) % 16 == 0 && (g->sB0 * es) % 16 == 0 && (g->sB1 * es) % 16 == 0,
+               "gemm: batch strides must keep 16-byte alignment");
+    MARS_CHECK(g->lda >= g->K && g->ldb >= g->K && g->ldc >= 1, "gemm: leading dimension smaller than K");
+    const int ntm = (g->M + BM - 1) / BM, ntn = (g->N + BN - 1) / BN;
+    dim3 grid(ntm * ntn, g->nb0 * g->nb1), block(THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (g->in_dtype == 1) {
+        if (g->out_dtype == 1) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, __bf16>), grid, block, 0, s, *g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, float>), grid, block, 0, s, *g);
+    } else {
+        if (g->out_dtype == 1) hipLaunchKernelGGL((gemm_tn_kernel<float, __bf16>), grid, block, 0, s, *g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, float>), grid, block, 0, s, *g);
+    }
+    MARS_LAUNCH_CHECK();
+    return 0;
+}

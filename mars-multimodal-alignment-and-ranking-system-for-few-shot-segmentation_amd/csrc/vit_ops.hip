@@ -1,0 +1,331 @@
+// Bandwidth-bound glue of the ViT towers: LayerNorm, patch extraction, prefix tokens,
+// transposes, row softmax, attention-map averaging, SwiGLU gate, casts, row L2 norm.
+// One wave per row wherever a row fits the 64 lanes' registers; 16-byte vector access
+// on the contiguous axis where the layout allows it.
+#include "common.h"
+#include "../../include/mars_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm
+template <typename TOUT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t xs,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        TOUT* __restrict__ y, int64_t ys, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)row * xs;
+    float v[32];  // D <= 2048
+    float s = 0.f;
+    const int n = (D + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < n) {
+            const int c = i * 64 + lane;
+            v[i] = c < D ? xr[c] : 0.f;
+            s += v[i];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < n) {
+            const int c = i * 64 + lane;
+            const float d = c < D ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    TOUT* yr = y + (int64_t)row * ys;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < n) {
+            const int c = i * 64 + lane;
+            if (c < D) st_from_f32<TOUT>(yr + c, (v[i] - mean) * rstd * w[c] + b[c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- im2col
+// one thread per output element of the real (unpadded) K range
+template <typename TOUT, typename TIN>
+__global__ void im2col_kernel(const TIN* __restrict__ img, int B, int C, int H, int W, int p,
+                              const float* __restrict__ mean, const float* __restrict__ stdv, float prescale,
+                              TOUT* __restrict__ out, int64_t ldo, int col_off) {
+    const int gw = W / p, gh = H / p;
+    const int K = C * p * p;
+    const int64_t total = (int64_t)B * gh * gw * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t tok = i / K;
+        const int dx = k % p, dy = (k / p) % p, c = k / (p * p);
+        const int px = (int)(tok % gw), py = (int)((tok / gw) % gh), b = (int)(tok / ((int64_t)gw * gh));
+        float v = (float)img[(((int64_t)b * C + c) * H + (py * p + dy)) * W + (px * p + dx)];
+        v = v * prescale;
+        if (mean) v = (v - mean[c]) / stdv[c];
+        st_from_f32<TOUT>(out + tok * ldo + col_off + k, v);
+    }
+}
+
+// ---------------------------------------------------------------- prefix tokens
+__global__ void prefix_tokens_kernel(float* X, int B, int T, int D, const float* cls, const float* pos0,
+                                     const float* regs, int num_regs) {
+    const int rows = 1 + num_regs;
+    const int64_t total = (int64_t)B * rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int r = (int)((i / D) % rows);
+        const int b = (int)(i / ((int64_t)D * rows));
+        float v;
+        if (r == 0) v = cls[d] + (pos0 ? pos0[d] : 0.f);
+        else v = regs[(int64_t)(r - 1) * D + d];
+        X[((int64_t)b * T + r) * D + d] = v;
+    }
+}
+
+// ---------------------------------------------------------------- transpose (32x32 tiles through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t ldi, int64_t sI0, int64_t sI1,
+                                                        T* __restrict__ out, int64_t ldo, int64_t sO0, int64_t sO1,
+                                                        int rows, int cols, int nb1) {
+    __shared__ T tile[32][33];
+    const int z = blockIdx.z, z0 = z / nb1, z1 = z % nb1;
+    const T* ib = in + z0 * sI0 + z1 * sI1;
+    T* ob = out + z0 * sO0 + z1 * sO1;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? ib[(int64_t)r * ldi + c] : (T)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;  // out[c][r]
+        if (c < cols && r < rows) ob[(int64_t)c * ldo + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+// ---------------------------------------------------------------- row softmax
+template <typename TOUT>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds, TOUT* __restrict__ P,
+                                                           int64_t ldp, int64_t nrows, int T, int causal) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int t = (int)(row % T);
+    const int lim = causal ? t + 1 : T;
+    const float* sr = S + row * lds;
+    float v[32];  // T <= 2048
+    float mx = -INFINITY;
+    const int n = (T + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < n) {
+            const int c = i * 64 + lane;
+            v[i] = c < lim ? sr[c] : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < n) {
+            v[i] = expf(v[i] - mx);
+            sum += v[i];
+        }
+    }
+    sum = wave_sum(sum);
+    TOUT* pr = P + row * ldp;
+    const int np = (int)((ldp + 63) / 64);
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+        if (i < np) {
+            const int c = i * 64 + lane;
+            if (c < ldp) st_from_f32<TOUT>(pr + c, (i < 32 && c < T) ? v[i < 32 ? i : 0] / sum : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- attention mean accumulate
+template <typename TIN>
+__global__ void attn_mean_accum_kernel(const TIN* __restrict__ P, int64_t ldp, int64_t hs, int H, int off, int Pn,
+                                       float scale, float* __restrict__ acc, int64_t lda) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= Pn) return;
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += ld_as_f32<TIN>(P + h * hs + (int64_t)(off + i) * ldp + off + j);
+    acc[(int64_t)i * lda + j] += scale * s;
+}
+
+template <typename T>
+__global__ void swiglu_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t M, int Hd, int64_t ldo) {
+    const int64_t total = M * Hd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / Hd;
+        const int j = (int)(i % Hd);
+        const float a = ld_as_f32<T>(x + m * 2 * Hd + j), b = ld_as_f32<T>(x + m * 2 * Hd + Hd + j);
+        st_from_f32<T>(out + m * ldo + j, a / (1.0f + expf(-a)) * b);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        st_from_f32<TO>(out + i, ld_as_f32<TI>(in + i));
+}
+
+// ---------------------------------------------------------------- row L2 normalise
+template <typename TOUT>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int64_t xb, int64_t xs, int row_off,
+                                                          int rows, int64_t total_rows, int D, TOUT* __restrict__ y, int64_t ys) {
+    const int64_t gr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gr >= total_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(gr / rows), r = (int)(gr % rows);
+    const float* xr = x + b * xb + (int64_t)(row_off + r) * xs;
+    float v[32];
+    float q = 0.f;
+    const int n = (D + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < n) {
+            const int c = i * 64 + lane;
+            v[i] = c < D ? xr[c] : 0.f;
+            q += v[i] * v[i];
+        }
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);  // F.normalize eps
+    TOUT* yr = y + gr * ys;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < n) {
+            const int c = i * 64 + lane;
+            if (c < D) st_from_f32<TOUT>(yr + c, v[i] / nrm);
+        }
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
+                                 int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream) {
+    MARS_CHECK(x && w && b && y, "layernorm: null pointer");
+    MARS_CHECK(rows > 0 && D > 0 && D <= 2048, "layernorm: D=%d out of range (1..2048)", D);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (out_dtype == 1) hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_im2col(const void* img, int in_u8, int B, int C, int H, int W, int p, const float* mean,
+                              const float* stdv, float prescale, void* out, int64_t ldo, int col_off, int out_dtype,
+                              void* stream) {
+    MARS_CHECK(img && out, "im2col: null pointer");
+    MARS_CHECK(p > 0 && H % p == 0 && W % p == 0, "im2col: image %dx%d is not a multiple of patch %d", H, W, p);
+    MARS_CHECK(col_off >= 0 && ldo >= (int64_t)C * p * p + col_off, "im2col: ldo too small");
+    MARS_CHECK((mean == nullptr) == (stdv == nullptr), "im2col: mean/std must come together");
+    const int64_t total = (int64_t)B * (H / p) * (W / p) * C * p * p;
+    dim3 grid(grid_for(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_u8) {
+        if (out_dtype == 1) hipLaunchKernelGGL((im2col_kernel<__bf16, uint8_t>), grid, block, 0, s, (const uint8_t*)img, B, C, H, W, p, mean, stdv, prescale, (__bf16*)out, ldo, col_off);
+        else hipLaunchKernelGGL((im2col_kernel<float, uint8_t>), grid, block, 0, s, (const uint8_t*)img, B, C, H, W, p, mean, stdv, prescale, (float*)out, ldo, col_off);
+    } else {
+        if (out_dtype == 1) hipLaunchKernelGGL((im2col_kernel<__bf16, float>), grid, block, 0, s, (const float*)img, B, C, H, W, p, mean, stdv, prescale, (__bf16*)out, ldo, col_off);
+        else hipLaunchKernelGGL((im2col_kernel<float, float>), grid, block, 0, s, (const float*)img, B, C, H, W, p, mean, stdv, prescale, (float*)out, ldo, col_off);
+    }
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_write_prefix_tokens(float* X, int B, int T, int D, const float* cls, const float* pos0,
+                                           const float* regs, int num_regs, void* stream) {
+    MARS_CHECK(X && cls, "prefix_tokens: null pointer");
+    MARS_CHECK(num_regs == 0 || regs, "prefix_tokens: register tokens missing");
+    MARS_CHECK(T >= 1 + num_regs, "prefix_tokens: T too small");
+    hipLaunchKernelGGL(prefix_tokens_kernel, dim3(grid_for((int64_t)B * (1 + num_regs) * D)), dim3(256), 0, (hipStream_t)stream,
+                       X, B, T, D, cls, pos0, regs, num_regs);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_transpose(const void* in, int64_t ldi, int64_t sI0, int64_t sI1, void* out, int64_t ldo,
+                                 int64_t sO0, int64_t sO1, int rows, int cols, int nb0, int nb1, int elem_size,
+                                 void* stream) {
+    MARS_CHECK(in && out, "transpose: null pointer");
+    MARS_CHECK(elem_size == 2 || elem_size == 4, "transpose: elem_size %d", elem_size);
+    MARS_CHECK(rows > 0 && cols > 0 && nb0 > 0 && nb1 > 0 && (int64_t)nb0 * nb1 <= 65535, "transpose: bad shape");
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nb0 * nb1), block(256);
+    if (elem_size == 2) hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)in, ldi, sI0, sI1, (uint16_t*)out, ldo, sO0, sO1, rows, cols, nb1);
+    else hipLaunchKernelGGL(transpose_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream, (const uint32_t*)in, ldi, sI0, sI1, (uint32_t*)out, ldo, sO0, sO1, rows, cols, nb1);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int nb, int T, int causal,
+                                    int out_dtype, void* stream) {
+    MARS_CHECK(S && P, "softmax_rows: null pointer");
+    MARS_CHECK(T > 0 && T <= 2048 && ldp >= T && ldp <= 2112 && lds >= T, "softmax_rows: T=%d ldp=%lld out of range", T, (long long)ldp);
+    const int64_t nrows = (int64_t)nb * T;
+    dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
+    if (out_dtype == 1) hipLaunchKernelGGL(softmax_rows_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, S, lds, (__bf16*)P, ldp, nrows, T, causal);
+    else hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, S, lds, (float*)P, ldp, nrows, T, causal);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_attn_mean_accum(const void* P, int64_t ldp, int64_t head_stride, int H, int off, int Pn,
+                                       float scale, float* acc, int64_t ldacc, int in_dtype, void* stream) {
+    MARS_CHECK(P && acc, "attn_mean_accum: null pointer");
+    MARS_CHECK(H > 0 && Pn > 0 && off >= 0 && ldp >= off + Pn && ldacc >= Pn, "attn_mean_accum: bad shape");
+    dim3 grid((Pn + 255) / 256, Pn), block(256);
+    if (in_dtype == 1) hipLaunchKernelGGL(attn_mean_accum_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)P, ldp, head_stride, H, off, Pn, scale, acc, ldacc);
+    else hipLaunchKernelGGL(attn_mean_accum_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)P, ldp, head_stride, H, off, Pn, scale, acc, ldacc);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_swiglu(const void* x12, void* out, int64_t ldo, int M, int Hd, int dtype, void* stream) {
+    MARS_CHECK(x12 && out && M > 0 && Hd > 0 && ldo >= Hd, "swiglu: bad arguments");
+    dim3 grid(grid_for((int64_t)M * Hd)), block(256);
+    if (dtype == 1) hipLaunchKernelGGL(swiglu_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)x12, (__bf16*)out, (int64_t)M, Hd, ldo);
+    else hipLaunchKernelGGL(swiglu_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x12, (float*)out, (int64_t)M, Hd, ldo);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream) {
+    MARS_CHECK(in && out && n > 0, "cast: bad arguments");
+    dim3 grid(grid_for(n)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == 0 && out_dtype == 1) hipLaunchKernelGGL((cast_kernel<float, __bf16>), grid, block, 0, s, (const float*)in, (__bf16*)out, n);
+    else if (in_dtype == 1 && out_dtype == 0) hipLaunchKernelGGL((cast_kernel<__bf16, float>), grid, block, 0, s, (const __bf16*)in, (float*)out, n);
+    else if (in_dtype == 0 && out_dtype == 0) hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, s, (const float*)in, (float*)out, n);
+    else hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), grid, block, 0, s, (const __bf16*)in, (__bf16*)out, n);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_l2norm_rows(const float* x, int64_t x_bstride, int64_t x_stride, int row_off, int B, int rows,
+                                   int D, void* y, int64_t y_stride, int out_dtype, void* stream) {
+    MARS_CHECK(x && y, "l2norm_rows: null pointer");
+    MARS_CHECK(B > 0 && rows > 0 && D > 0 && D <= 2048, "l2norm_rows: bad shape");
+    const int64_t total = (int64_t)B * rows;
+    dim3 grid((unsigned)((total + 3) / 4)), block(256);
+    if (out_dtype == 1) hipLaunchKernelGGL(l2norm_rows_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_bstride, x_stride, row_off, rows, total, D, (__bf16*)y, y_stride);
+    else hipLaunchKernelGGL(l2norm_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, x, x_bstride, x_stride, row_off, rows, total, D, (float*)y, y_stride);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,189 @@
+"""Per-proposal scoring, ranking and merging on the GPU (+ exact EMD on host threads).
+
+Interface of /root/reference/mars/components/FilteringMergingModule.py:15-221:
+``compute(query_img, mask_proposals, support_mask, cost_matrix, patch_features_spatial_dimension,
+vva, vta, text) -> [H, W]``.
+
+Data flow per query: proposals are read once by the pooling kernel (patch occupancy bits) and
+once by the alpha-plane resampler; the N AlphaCLIP passes run as one batch while the host
+solves the N transport problems; a single-block kernel combines the four scores in float64,
+ranks them and decides the kept set; the merge kernel ORs the kept proposals.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Optional, Union
+
+import torch
+
+from ... import ops, resample
+from .VisualVisualAlignmentModule import SimilarityHandle
+from .VisualTextAlignmentModule import CLIP_MEAN, CLIP_STD
+
+
+class FilteringMergingModule:
+    def __init__(self, alpha_clip_model, img_transforms, mask_transforms, alpha: float, static_threshold: float,
+                 dynamic_threshold: float, device, tokenizer: Optional[Callable] = None, emd_threads: int = 0):
+        self.alpha_clip_model = alpha_clip_model
+        self.img_transforms = img_transforms      # API parity; both transforms run as kernels
+        self.mask_transforms = mask_transforms
+        self.alpha = alpha
+        self.static_threshold = static_threshold
+        self.dynamic_threshold = dynamic_threshold
+        self.device = torch.device(device)
+        self.alpha_clip_batch_size = 128
+        if tokenizer is None:
+            from ...synth import tokenize as tokenizer
+        self.tokenizer = tokenizer
+        self.emd_threads = emd_threads or int(os.environ.get("MARS_EMD_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        self._mean = torch.tensor(CLIP_MEAN, dtype=torch.float32, device=self.device)
+        self._std = torch.tensor(CLIP_STD, dtype=torch.float32, device=self.device)
+        self._tables: Dict = {}
+        self._ws: Dict = {}
+        self.last = {}
+
+    # ---------------------------------------------------------------- tables / buffers
+    def _aa_table(self, n_in, n_out):
+        key = ("aa", n_in, n_out)
+        if key not in self._tables:
+            t = resample.torch_aa_table(n_in, n_out, "bilinear")
+            self._tables[key] = tuple(torch.from_numpy(a).to(self.device).contiguous() for a in t)
+        return self._tables[key]
+
+    def _pil_table(self, n_in, n_out):
+        key = ("pil", n_in, n_out)
+        if key not in self._tables:
+            t = resample.pil_table_u8(n_in, n_out)
+            self._tables[key] = tuple(torch.from_numpy(a).to(self.device).contiguous() for a in t)
+        return self._tables[key]
+
+    def _buffers(self, N: int, S: int, P: int, R: int):
+        key = (N, S, P, R)
+        w = self._ws.get(key)
+        if w is None:
+            dev = self.device
+            res = self.alpha_clip_model.input_resolution
+            f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+            w = self._ws[key] = dict(
+                bits=torch.zeros(N, P, dtype=torch.uint8, device=dev),
+                bits_host=torch.zeros(N, P, dtype=torch.uint8).pin_memory(),
+                fg_host=torch.zeros(R, dtype=torch.uint8).pin_memory(),
+                sbits=torch.zeros(R, dtype=torch.uint8, device=dev),
+                cnt=torch.zeros(N, dtype=torch.int32, device=dev), ucnt=torch.zeros(1, dtype=torch.int32, device=dev),
+                svv=f(N), svt=f(N), aclip=f(N),
+                emd=torch.zeros(N, dtype=torch.float64, device=dev),
+                score=torch.zeros(N, dtype=torch.float64, device=dev),
+                order=torch.zeros(N, dtype=torch.int32, device=dev),
+                keep=torch.zeros(N, dtype=torch.uint8, device=dev),
+                img_u8=torch.zeros(3, S, S, dtype=torch.uint8, device=dev),
+                img_tmp=torch.zeros(3, S, res, dtype=torch.uint8, device=dev),
+                img_res=torch.zeros(1, 3, res, res, dtype=torch.uint8, device=dev),
+                a_tmp=f(min(N, self.alpha_clip_batch_size), S, res),
+                alpha=f(min(N, self.alpha_clip_batch_size), 1, res, res),
+                feats=f(N, self.alpha_clip_model.cfg.embed_dim),
+                merged=f(S, S),
+            )
+        return w
+
+    # ---------------------------------------------------------------- reference API
+    def compute(self, query_img, mask_proposals, support_mask, cost_matrix, patch_features_spatial_dimension: int,
+                vva, vta, text: List[str]) -> torch.Tensor:
+        self._score_proposals(query_img, mask_proposals, support_mask, cost_matrix, patch_features_spatial_dimension,
+                              vva, vta, text)
+        return self._merge_masks(mask_proposals)
+
+    def _compute_alphaclip_text_feats(self, text: List[str]) -> torch.Tensor:
+        """Lines 171-181 (normalisation happens inside the cosine-score kernel)."""
+        return self.alpha_clip_model.encode_text(self.tokenizer(text))
+
+    def _image_u8(self, image: torch.Tensor, w: dict) -> torch.Tensor:
+        """Image branch of the AlphaCLIP transform (utils/backbone_loader.py:172-180): float image ->
+        8-bit (x255, truncated) -> Pillow bicubic resize -> 8-bit [1,3,R,R]; /255 and the CLIP
+        normalisation are fused into the patch extraction."""
+        C, S, S2 = image.shape
+        assert S == S2, "the synthetic and benchmark episodes are square; centre crop is then the identity"
+        res = self.alpha_clip_model.input_resolution
+        ops.f32_to_u8(image.contiguous().float(), w["img_u8"])
+        t = self._pil_table(S, res)
+        ops.resample_axis_u8(w["img_u8"], C, S, S, 1, t, w["img_tmp"])
+        ops.resample_axis_u8(w["img_tmp"], C, S, res, 0, t, w["img_res"])
+        return w["img_res"]
+
+    def _compute_alphaclip_vis_feats(self, image: torch.Tensor, masks: torch.Tensor, w: Optional[dict] = None) -> torch.Tensor:
+        """Lines 183-207: one AlphaCLIP pass per proposal (batched), un-normalised features [N, E]."""
+        N, S, _ = masks.shape
+        if w is None:
+            w = self._buffers(N, S, 1, 1)
+        res = self.alpha_clip_model.input_resolution
+        img = self._image_u8(image, w)
+        t = self._aa_table(S, res)
+        bs = self.alpha_clip_batch_size
+        for i in range(0, N, bs):
+            n = min(bs, N - i)
+            chunk = masks[i:i + n].contiguous().float()
+            # mask branch (backbone_loader.py:182-186): u8 quantise, bilinear antialiased resize, (x-0.5)/0.26
+            ops.resample_axis(chunk, n, S, S, 1, t, w["a_tmp"], quant_u8=True)
+            ops.resample_axis(w["a_tmp"], n, S, res, 0, t, w["alpha"], shift=0.5, scale=0.26)
+            f = self.alpha_clip_model.visual(img, w["alpha"][:n], mean=self._mean, std=self._std)
+            w["feats"][i:i + n].copy_(f)
+        return w["feats"]
+
+    def _score_proposals(self, query_img, mask_proposals, support_mask, cost_matrix, G: int, vva, vta, text):
+        dev = self.device
+        masks = mask_proposals.to(dev).contiguous().float()
+        N, S, _ = masks.shape
+        P = G * G
+        smask = support_mask.to(dev)[0].contiguous().float()       # [ns, S, S]
+        R = smask.shape[0] * P
+        w = self._buffers(N, S, P, R)
+        # lines 73-81, 104-110: patch occupancy of the support masks and of every proposal
+        ops.pool_masks(smask, G, w["sbits"])
+        ops.pool_masks(masks, G, w["bits"])
+        w["bits_host"].copy_(w["bits"], non_blocking=True)
+        w["fg_host"].copy_(w["sbits"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ops.proposal_stats(w["bits"], N, P, vva.to(dev).contiguous().float().view(-1), vta.to(dev).contiguous().float().view(-1),
+                           w["cnt"], w["svv"], w["svt"], w["ucnt"])
+        # lines 90-97: AlphaCLIP text/visual features and their cosine (queued on the GPU ...)
+        tfeat = self._compute_alphaclip_text_feats(text)
+        feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w)
+        ops.cosine_scores(feats, tfeat, w["aclip"])
+        # lines 112-116, 142-169: ... while the host solves the N transport problems
+        ev.synchronize()
+        if isinstance(cost_matrix, SimilarityHandle):
+            emd = ops.emd_scores_host(cost_matrix.wait(), w["fg_host"], w["bits_host"], self.emd_threads, is_cost=False)
+        else:
+            cm = cost_matrix.detach().cpu().float().contiguous()
+            emd = ops.emd_scores_host(cm, w["fg_host"], w["bits_host"], self.emd_threads, is_cost=True)
+        w["emd"].copy_(emd, non_blocking=False)
+        # lines 118-138, 213-217: combine, rank, keep
+        ops.rank(w["emd"], w["aclip"], w["cnt"], w["svv"], w["svt"], w["ucnt"], N, self.alpha, self.static_threshold,
+                 self.dynamic_threshold, w["score"], w["order"], w["keep"])
+        self.last = dict(w=w, masks=masks, N=N)
+        return w
+
+    def _merge_masks(self, ranked_masks=None) -> torch.Tensor:
+        """Lines 209-221 on the keep flags the ranking kernel produced."""
+        w, masks = self.last["w"], self.last["masks"]
+        ops.merge_masks(masks, w["keep"], w["merged"])
+        return w["merged"]
+
+    def scores(self) -> dict:
+        """Host copies of the per-proposal quantities of the last call (for tests and logging)."""
+        w, N = self.last["w"], self.last["N"]
+        return {k: w[k][:N].cpu() for k in ("emd", "aclip", "cnt", "svv", "svt", "score", "order", "keep")} | {
+            "ucnt": w["ucnt"].cpu(), "feats": w["feats"][:N].cpu()}
+
+
+def build_filtering_and_merging_module(args, state_dict=None):
+    """Reference builder (lines 223-246) with weights injectable through ``state_dict``."""
+    from ...utils.backbone_loader import BackboneLoader
+    model, transforms = BackboneLoader.load_backbone(
+        backbone_name="alphaclip", backbone_size=getattr(args, "alphaclip_backbone", "ViT-L/14@336px"), device=args.device,
+        backbone_weights_path=getattr(args, "alphaclip_weights", None),
+        encoder_kwargs={"device": args.device, "download_root": getattr(args, "models_path", None), "state_dict": state_dict,
+                        "dtype": getattr(args, "dtype", torch.float32)})
+    return FilteringMergingModule(
+        alpha_clip_model=model, img_transforms=transforms[0], mask_transforms=transforms[1], alpha=args.alpha_coverage,
+        static_threshold=args.static_threshold, dynamic_threshold=args.dynamic_threshold, device=args.device)

@@ -1,0 +1,551 @@
+"""DINOv2 / CLIP / AlphaCLIP encoders on the HIP kernels, with the reference's method names.
+
+The classes duck-type what ``BackboneLoader.load_backbone`` returns in the reference
+(/root/reference/utils/backbone_loader.py:17-52):
+
+* ``DinoVisionTransformer``: ``forward_features(x)['x_prenorm']``, ``get_last_self_attention(x)``,
+  ``embed_dim``, ``patch_size``, ``num_register_tokens``, ``family``
+  (/root/reference/dinov2/models/vision_transformer.py:266-286,352-370)
+* ``CLIP``: ``encode_image(img, H, W)``, ``encode_text``, ``forward_last_layer``, ``visual.patch_size``, ``dtype``
+  (/root/reference/clip/model.py:483-524)
+* ``AlphaCLIP``: ``visual(image, alpha)``, ``encode_text`` (/root/reference/alpha_clip/model.py:358-386,525-538)
+
+plus fused entry points the components use so that attention maps are averaged on the
+fly instead of being materialised.  torch is used for allocation, parameter
+preparation at load time and views; every per-call computation is a C-ABI kernel.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .hip import ACT_GELU, ACT_NONE, ACT_QUICKGELU
+from .synth import ClipCfg, DinoCfg
+
+SD = Dict[str, torch.Tensor]
+
+
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def flash_enabled() -> bool:
+    return os.environ.get("MARS_FLASH", "1") != "0"
+
+
+class Lin:
+    """One nn.Linear: weight [N, Kpad] in the compute dtype (zero padded along K), bias f32."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], dtype, device):
+        N, K = w.shape
+        Kp = _pad_to(K, 64)
+        wp = torch.zeros(N, Kp, dtype=torch.float32)
+        wp[:, :K] = w.float()
+        self.w = wp.to(device=device, dtype=dtype).contiguous()
+        self.b = b.float().to(device).contiguous() if b is not None else None
+        self.N, self.K, self.Kp = N, K, Kp
+
+
+class Norm:
+    def __init__(self, sd: SD, prefix: str, device, eps: float):
+        self.w = sd[prefix + ".weight"].float().to(device).contiguous()
+        self.b = sd[prefix + ".bias"].float().to(device).contiguous()
+        self.eps = eps
+
+
+class Block:
+    pass
+
+
+class Tower:
+    """A stack of pre-LN transformer blocks with 64-wide heads over a f32 residual stream."""
+
+    def __init__(self, D: int, heads: int, device, dtype):
+        assert D == heads * 64, "the attention kernels are written for head_dim 64"
+        self.D, self.H, self.device, self.dtype = D, heads, device, dtype
+        self.blocks: List[Block] = []
+        self._ws: Dict[Tuple[int, int, int], dict] = {}
+
+    # ---- workspaces (allocated once per shape; pads stay zero) ----
+    def ws(self, B: int, T: int, hidden: int) -> dict:
+        key = (B, T, hidden)
+        w = self._ws.get(key)
+        if w is None:
+            dev, dtp, D, H = self.device, self.dtype, self.D, self.H
+            M, Tp = B * T, _pad_to(T, 64)
+            w = dict(
+                xn=torch.zeros(M, D, dtype=dtp, device=dev),
+                qkv=torch.zeros(M, 3 * D, dtype=dtp, device=dev),
+                ao=torch.zeros(M, D, dtype=dtp, device=dev),
+                hid=torch.zeros(M, hidden, dtype=dtp, device=dev),
+                lse=torch.zeros(B * H, T, dtype=torch.float32, device=dev),
+                Tp=Tp,
+            )
+            self._ws[key] = w
+        return w
+
+    def ws_unfused(self, w: dict, B: int, T: int):
+        if "S" not in w:
+            dev, dtp, H, Tp = self.device, self.dtype, self.H, w["Tp"]
+            w["S"] = torch.zeros(B * H, T, Tp, dtype=torch.float32, device=dev)
+            w["P"] = torch.zeros(B * H, T, Tp, dtype=dtp, device=dev)
+            w["VT"] = torch.zeros(B * H, 64, Tp, dtype=dtp, device=dev)
+        return w
+
+    # ---- attention ----
+    def attention(self, w: dict, B: int, T: int, *, causal: bool, need_probs: bool, mean_acc=None):
+        """qkv -> ao.  ``mean_acc`` = (acc [Pn,Pn] f32, off, Pn, scale): adds scale * sum over heads of the
+        probabilities of image 0 restricted to tokens off..off+Pn."""
+        D, H, Tp = self.D, self.H, w["Tp"]
+        use_flash = self.dtype == torch.bfloat16 and flash_enabled() and not need_probs
+        if use_flash:
+            ops.flash_attn(w["qkv"], w["ao"], w["lse"], B, T, H, causal)
+            if mean_acc is not None:
+                acc, off, Pn, scale = mean_acc
+                ops.flash_attn_mean(w["qkv"], w["lse"], T, H, off, Pn, scale, acc)
+            return None
+        self.ws_unfused(w, B, T)
+        qkv, S, P, VT = w["qkv"], w["S"], w["P"], w["VT"]
+        # S = (q k^T) / 8 per (image, head)
+        ops.gemm(qkv, qkv, S, T, T, 64, lda=3 * D, ldb=3 * D, ldc=Tp, a_off=0, b_off=D, nb0=B, nb1=H,
+                 sA=(T * 3 * D, 64), sB=(T * 3 * D, 64), sC=(H * T * Tp, T * Tp), alpha=0.125)
+        ops.softmax_rows(S, P, B * H, T, Tp, causal)
+        ops.transpose_raw(qkv, 2 * D, 3 * D, (T * 3 * D, 64), VT, 0, Tp, (H * 64 * Tp, 64 * Tp), T, 64, B, H)
+        ops.gemm(P, VT, w["ao"], T, 64, Tp, lda=Tp, ldb=Tp, ldc=D, nb0=B, nb1=H, sA=(H * T * Tp, T * Tp),
+                 sB=(H * 64 * Tp, 64 * Tp), sC=(T * D, 64))
+        if mean_acc is not None:
+            acc, off, Pn, scale = mean_acc
+            ops.attn_mean_accum(P, 0, Tp, T * Tp, H, off, Pn, scale, acc)
+        return P
+
+    # ---- one block ----
+    def block_forward(self, x: torch.Tensor, blk: Block, *, causal=False, need_probs=False, mean_acc=None, keep=None):
+        """x f32 [B,T,D], updated in place.  ``keep`` (dict) receives intermediates for the CAM backward."""
+        B, T, D = x.shape
+        w = self.ws(B, T, blk.hidden_alloc)
+        x2 = x.view(B * T, D)
+        ops.layernorm(x2, blk.ln1.w, blk.ln1.b, w["xn"], blk.ln1.eps)
+        ops.linear(w["xn"], blk.qkv.w, w["qkv"], bias=blk.qkv.b)
+        P = self.attention(w, B, T, causal=causal, need_probs=need_probs, mean_acc=mean_acc)
+        if keep is not None:
+            keep["ln1"] = w["xn"].clone(); keep["qkv"] = w["qkv"].clone(); keep["ao"] = w["ao"].clone()
+        ops.linear(w["ao"], blk.proj.w, x2, bias=blk.proj.b, gamma=blk.ls1, residual=x2)
+        if keep is not None:
+            keep["x1"] = x2.clone()
+        ops.layernorm(x2, blk.ln2.w, blk.ln2.b, w["xn"], blk.ln2.eps)
+        if blk.ffn == "swiglu":
+            ops.linear(w["xn"], blk.fc1.w, w["hid"], bias=blk.fc1.b)          # [M, 2*hidden]
+            g = w.get("gate")
+            if g is None:
+                g = w["gate"] = torch.zeros(B * T, blk.fc2.Kp, dtype=self.dtype, device=self.device)
+            ops.swiglu(w["hid"], g)                                            # pad columns stay zero
+            ops.linear(g, blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, residual=x2)
+        else:
+            if keep is not None:
+                pre = w.setdefault("pre", torch.zeros(B * T, blk.fc1.N, dtype=self.dtype, device=self.device))
+                ops.linear(w["xn"], blk.fc1.w, pre, bias=blk.fc1.b)
+                keep["ln2"] = w["xn"].clone(); keep["pre"] = pre.clone()
+            ops.linear(w["xn"], blk.fc1.w, w["hid"], bias=blk.fc1.b, act=blk.act)
+            ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, residual=x2)
+        return P
+
+
+def _make_block(sd: SD, names: dict, D: int, device, dtype, eps: float, act: int, ffn: str = "mlp") -> Block:
+    b = Block()
+    b.ln1 = Norm(sd, names["ln1"], device, eps)
+    b.ln2 = Norm(sd, names["ln2"], device, eps)
+    b.qkv = Lin(sd[names["qkv_w"]], sd[names["qkv_b"]], dtype, device)
+    b.proj = Lin(sd[names["proj"] + ".weight"], sd[names["proj"] + ".bias"], dtype, device)
+    b.fc1 = Lin(sd[names["fc1"] + ".weight"], sd[names["fc1"] + ".bias"], dtype, device)
+    b.fc2 = Lin(sd[names["fc2"] + ".weight"], sd[names["fc2"] + ".bias"], dtype, device)
+    b.ls1 = sd[names["ls1"]].float().to(device).contiguous() if names.get("ls1") else None
+    b.ls2 = sd[names["ls2"]].float().to(device).contiguous() if names.get("ls2") else None
+    b.act, b.ffn = act, ffn
+    b.hidden = b.fc2.K
+    b.hidden_alloc = b.fc1.N
+    return b
+
+
+# ======================================================================================
+# DINOv2
+# ======================================================================================
+class DinoVisionTransformer:
+    family = "vits_dino2"
+
+    def __init__(self, cfg: DinoCfg, sd: SD, device="cuda", dtype=torch.float32):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.embed_dim, self.patch_size, self.num_register_tokens = cfg.embed_dim, cfg.patch_size, cfg.num_regs
+        self.num_heads, self.n_blocks = cfg.num_heads, cfg.depth
+        D, p = cfg.embed_dim, cfg.patch_size
+        self.tower = Tower(D, cfg.num_heads, self.device, dtype)
+        for i in range(cfg.depth):
+            pre = f"blocks.{i}"
+            names = dict(ln1=pre + ".norm1", ln2=pre + ".norm2", qkv_w=pre + ".attn.qkv.weight", qkv_b=pre + ".attn.qkv.bias",
+                         proj=pre + ".attn.proj", ls1=pre + ".ls1.gamma", ls2=pre + ".ls2.gamma")
+            if cfg.ffn == "mlp":
+                names.update(fc1=pre + ".mlp.fc1", fc2=pre + ".mlp.fc2")
+            else:
+                names.update(fc1=pre + ".mlp.w12", fc2=pre + ".mlp.w3")
+            self.tower.blocks.append(_make_block(sd, names, D, self.device, dtype, 1e-6, ACT_GELU, cfg.ffn))
+        self.pe = Lin(sd["patch_embed.proj.weight"].reshape(D, 3 * p * p), sd["patch_embed.proj.bias"], dtype, self.device)
+        self.cls = sd["cls_token"].reshape(D).float().to(self.device)
+        pos = sd["pos_embed"].reshape(-1, D).float().to(self.device).contiguous()
+        self.pos0, self.pos_patch = pos[0].contiguous(), pos[1:].contiguous()
+        self.regs = sd["register_tokens"].reshape(-1, D).float().to(self.device).contiguous() if cfg.num_regs else None
+        self.norm = Norm(sd, "norm", self.device, 1e-6)
+        self._cols: Dict[int, torch.Tensor] = {}
+
+    def _tokens(self, x: torch.Tensor, mean=None, std=None) -> torch.Tensor:
+        """prepare_tokens_with_masks (vision_transformer.py:223-243) for inputs of the constructor size."""
+        B, C, H, W = x.shape
+        cfg = self.cfg
+        assert C == 3 and H == cfg.img_size and W == cfg.img_size, "input must match the constructor image size"
+        Pn, D, R = cfg.grid * cfg.grid, cfg.embed_dim, cfg.num_regs
+        T = 1 + R + Pn
+        cols = self._cols.get(B)
+        if cols is None:
+            cols = self._cols[B] = torch.zeros(B * Pn, self.pe.Kp, dtype=self.dtype, device=self.device)
+        ops.im2col(x.contiguous().float(), cfg.patch_size, cols, mean=mean, std=std)
+        X = torch.empty(B, T, D, dtype=torch.float32, device=self.device)
+        ops.gemm(cols, self.pe.w, X, Pn, D, self.pe.Kp, lda=self.pe.Kp, ldb=self.pe.Kp, ldc=D, c_off=(1 + R) * D, nb0=B,
+                 sA=(Pn * self.pe.Kp, 0), sC=(T * D, 0), bias=self.pe.b, residual=self.pos_patch, ldr=D)
+        ops.write_prefix_tokens(X, self.cls, self.pos0, self.regs)
+        return X
+
+    def forward_tokens(self, x, mean=None, std=None, mean_attn: Optional[Tuple[torch.Tensor, int]] = None):
+        """Run every block.  ``mean_attn`` = (acc [P,P] zeroed f32, last_n): accumulates the mean over the
+        last n blocks and all heads of the patch-to-patch attention of image 0."""
+        X = self._tokens(x, mean, std)
+        L = self.cfg.depth
+        for i, blk in enumerate(self.tower.blocks):
+            ma = None
+            if mean_attn is not None and i >= L - mean_attn[1]:
+                n = min(mean_attn[1], L)
+                ma = (mean_attn[0], 1 + self.cfg.num_regs, self.cfg.grid ** 2, 1.0 / (n * self.cfg.num_heads))
+            self.tower.block_forward(X, blk, mean_acc=ma)
+        return X
+
+    def forward_features(self, x: torch.Tensor, masks=None) -> dict:
+        assert masks is None
+        X = self.forward_tokens(x)
+        B, T, D = X.shape
+        xn = torch.empty_like(X)
+        ops.layernorm(X.view(B * T, D), self.norm.w, self.norm.b, xn.view(B * T, D), self.norm.eps)
+        R = self.num_register_tokens
+        return {"x_norm_clstoken": xn[:, 0], "x_norm_regtokens": xn[:, 1:R + 1], "x_norm_patchtokens": xn[:, R + 1:],
+                "x_prenorm": X, "masks": masks}
+
+    def get_last_self_attention(self, x: torch.Tensor, masks=None):
+        """Tuple of per-block attention probabilities [B, heads, T, T] (vision_transformer.py:352-370).
+        Materialises them, as the reference does; the components use ``forward_tokens(mean_attn=...)``."""
+        X = self._tokens(x)
+        B, T, _ = X.shape
+        out = []
+        for blk in self.tower.blocks:
+            P = self.tower.block_forward(X, blk, need_probs=True)
+            out.append(P.view(B, self.num_heads, T, -1)[..., :T].float().clone())
+        return tuple(out)
+
+
+# ======================================================================================
+# CLIP towers (CLIP-ES flavour and AlphaCLIP)
+# ======================================================================================
+class _TextTower:
+    def __init__(self, cfg: ClipCfg, sd: SD, device, dtype):
+        self.cfg, self.device, self.dtype = cfg, device, dtype
+        W = cfg.transformer_width
+        self.tower = Tower(W, cfg.transformer_heads, device, dtype)
+        for i in range(cfg.transformer_layers):
+            pre = f"transformer.resblocks.{i}"
+            names = dict(ln1=pre + ".ln_1", ln2=pre + ".ln_2", qkv_w=pre + ".attn.in_proj_weight", qkv_b=pre + ".attn.in_proj_bias",
+                         proj=pre + ".attn.out_proj", fc1=pre + ".mlp.c_fc", fc2=pre + ".mlp.c_proj")
+            self.tower.blocks.append(_make_block(sd, names, W, device, dtype, 1e-5, ACT_QUICKGELU))
+        self.tok = sd["token_embedding.weight"].float().to(device)
+        self.pos = sd["positional_embedding"].float().to(device)
+        self.ln_final = Norm(sd, "ln_final", device, 1e-5)
+        self.proj_t = Lin(sd["text_projection"].t().contiguous(), None, torch.float32, device)  # [E, W]
+
+    def encode_text(self, tokens: torch.Tensor) -> torch.Tensor:
+        """encode_text (clip/model.py:486-499): causal transformer, EOT feature, text_projection."""
+        tokens_cpu = tokens.cpu()
+        n, L = tokens_cpu.shape
+        idx = tokens_cpu.long().to(self.device)
+        X = (self.tok.index_select(0, idx.reshape(-1)).view(n, L, -1) + self.pos).contiguous()  # embedding gather
+        for blk in self.tower.blocks:
+            self.tower.block_forward(X, blk, causal=True)
+        eot = tokens_cpu.argmax(dim=-1)
+        rows = (torch.arange(n) * L + eot).to(self.device)
+        W = self.cfg.transformer_width
+        sel = X.view(n * L, W).index_select(0, rows).contiguous()
+        y = torch.empty(n, W, dtype=torch.float32, device=self.device)
+        ops.layernorm(sel, self.ln_final.w, self.ln_final.b, y, self.ln_final.eps)
+        out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        ops.linear(y, self.proj_t.w, out)
+        return out
+
+
+class _Visual:
+    """Attribute bag mirroring ``model.visual`` of the reference for the names the callers touch."""
+    pass
+
+
+class CLIP(_TextTower):
+    """CLIP-ES style CLIP used for the visual-text alignment."""
+
+    def __init__(self, cfg: ClipCfg, sd: SD, device="cuda", dtype=torch.float32):
+        device = torch.device(device)
+        super().__init__(cfg, sd, device, dtype)
+        W, p = cfg.vision_width, cfg.vision_patch_size
+        self.vtower = Tower(W, cfg.vision_heads, device, dtype)
+        self.vtower32 = self.vtower if dtype == torch.float32 else Tower(W, cfg.vision_heads, device, torch.float32)
+        for i in range(cfg.vision_layers):
+            pre = f"visual.transformer.resblocks.{i}"
+            names = dict(ln1=pre + ".ln_1", ln2=pre + ".ln_2", qkv_w=pre + ".attn.in_proj_weight", qkv_b=pre + ".attn.in_proj_bias",
+                         proj=pre + ".attn.out_proj", fc1=pre + ".mlp.c_fc", fc2=pre + ".mlp.c_proj")
+            last = i == cfg.vision_layers - 1
+            # the last block (forward_last_layer + GradCAM) always runs in f32
+            self.vtower.blocks.append(_make_block(sd, names, W, device, torch.float32 if last else dtype, 1e-5, ACT_QUICKGELU))
+        lp = f"visual.transformer.resblocks.{cfg.vision_layers - 1}"
+        # transposed f32 copies of the last block's weights: backward products as TN GEMMs
+        self.last_T = dict(
+            in_proj=sd[lp + ".attn.in_proj_weight"].float().t().contiguous().to(device),     # [D, 3D]
+            out_proj=sd[lp + ".attn.out_proj.weight"].float().t().contiguous().to(device),   # [D, D]
+            c_fc=sd[lp + ".mlp.c_fc.weight"].float().t().contiguous().to(device),            # [D, 4D]
+            c_proj=sd[lp + ".mlp.c_proj.weight"].float().t().contiguous().to(device),        # [4D, D]
+        )
+        self.conv1 = Lin(sd["visual.conv1.weight"].reshape(W, 3 * p * p), None, dtype, device)
+        self.class_embedding = sd["visual.class_embedding"].float().to(device)
+        self.pos_table = sd["visual.positional_embedding"].float()  # CPU: resized per grid on demand
+        self.ln_pre = Norm(sd, "visual.ln_pre", device, 1e-5)
+        self.ln_post = Norm(sd, "visual.ln_post", device, 1e-5)
+        self.vproj = sd["visual.proj"].float().to(device).contiguous()  # [W, E]
+        self.logit_scale_exp = float(sd["logit_scale"].float().exp())
+        self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._cols: Dict[int, torch.Tensor] = {}
+        self.visual = _Visual()
+        self.visual.patch_size = p
+        self.visual.input_resolution = cfg.image_resolution
+        self.visual.output_dim = cfg.embed_dim
+
+    def _pos(self, gh: int, gw: int) -> torch.Tensor:
+        """upsample_pos_emb (clip/model.py:99-115): bilinear resize of the patch table and a round trip
+        through fp16; input independent, so prepared once per grid."""
+        key = (gh, gw)
+        if key not in self._pos_cache:
+            emb = self.pos_table
+            first, rest = emb[:1], emb[1:]
+            n, d = rest.shape
+            s = int(math.isqrt(n))
+            rest = rest.permute(1, 0).reshape(1, d, s, s)
+            rest = F.interpolate(rest, size=(gh, gw), mode="bilinear", align_corners=False)
+            rest = rest.reshape(d, -1).permute(1, 0)
+            self._pos_cache[key] = torch.cat([first, rest], 0).half().float().to(self.device).contiguous()
+        return self._pos_cache[key]
+
+    def _vision_tokens(self, image: torch.Tensor, mean=None, std=None) -> torch.Tensor:
+        B, C, H, W = image.shape
+        p, D = self.cfg.vision_patch_size, self.cfg.vision_width
+        gh, gw = H // p, W // p
+        Pn, T = gh * gw, gh * gw + 1
+        pos = self._pos(gh, gw)
+        key = (B, Pn)
+        cols = self._cols.get(key)
+        if cols is None:
+            cols = self._cols[key] = torch.zeros(B * Pn, self.conv1.Kp, dtype=self.dtype, device=self.device)
+        ops.im2col(image.contiguous().float(), p, cols, mean=mean, std=std)
+        X = torch.empty(B, T, D, dtype=torch.float32, device=self.device)
+        ops.gemm(cols, self.conv1.w, X, Pn, D, self.conv1.Kp, lda=self.conv1.Kp, ldb=self.conv1.Kp, ldc=D, c_off=D, nb0=B,
+                 sA=(Pn * self.conv1.Kp, 0), sC=(T * D, 0), residual=pos, r_off=D, ldr=D)
+        ops.write_prefix_tokens(X, self.class_embedding, pos[0], None)
+        X2 = X.view(B * T, D)
+        ops.layernorm(X2, self.ln_pre.w, self.ln_pre.b, X2, self.ln_pre.eps)
+        return X
+
+    def encode_image_tokens(self, image, mean=None, std=None, mean_attn=None, need_probs=False):
+        """All blocks but the last.  Returns (X [B,T,D] f32, list of materialised probabilities or None)."""
+        X = self._vision_tokens(image, mean, std)
+        B, T, _ = X.shape
+        L = self.cfg.vision_layers
+        probs = [] if need_probs else None
+        for i in range(L - 1):
+            ma = None
+            if mean_attn is not None and i >= L - mean_attn[1]:
+                ma = (mean_attn[0], 1, T - 1, 1.0 / (min(mean_attn[1], L) * self.cfg.vision_heads))
+            P = self.vtower.block_forward(X, self.vtower.blocks[i], need_probs=need_probs, mean_acc=ma)
+            if need_probs:
+                probs.append(P.view(B, self.cfg.vision_heads, T, -1)[..., :T].float().mean(dim=1))
+        return X, probs
+
+    def encode_image(self, image, H, W, extract=None):
+        """encode_image(img, H, W) (clip/model.py:483-484,357-383): tokens in LND layout and the list of
+        head-averaged attention maps of every block but the last."""
+        X, probs = self.encode_image_tokens(image, need_probs=True)
+        return X.permute(1, 0, 2), probs
+
+    def forward_last_layer(self, image_features, text_features):
+        """forward_last_layer (clip/model.py:501-524) on the LND tokens ``encode_image`` returned: last
+        block in f32, ln_post, patch-token mean, projection, softmax over the {fg, bg} text pair.
+        Returns (logits [B,2], head-averaged attention [B,T,T])."""
+        return self._last_layer(image_features.permute(1, 0, 2).contiguous().float(), text_features)
+
+    def _last_layer(self, X, text_features, mean_attn=None, keep=None):
+        """Same on batch-major tokens X f32 [B,T,D] (modified in place)."""
+        B, T, D = X.shape
+        blk = self.vtower.blocks[-1]
+        P = self.vtower32.block_forward(X, blk, need_probs=True, mean_acc=mean_attn, keep=keep)
+        H = self.cfg.vision_heads
+        attn = P.view(B, H, T, -1)[..., :T].mean(dim=1)
+        y = torch.empty(B * T, D, dtype=torch.float32, device=self.device)
+        ops.layernorm(X.view(B * T, D), self.ln_post.w, self.ln_post.b, y, self.ln_post.eps)
+        logits = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+        f = torch.empty(D, dtype=torch.float32, device=self.device)
+        df = torch.empty(D, dtype=torch.float32, device=self.device)
+        assert B == 1 and text_features.shape[0] == 2, "the CAM head is written for one image and the {fg, bg} text pair"
+        ops.col_mean(y, 1, T, f)
+        ops.cam_head(f, self.vproj, text_features.float().contiguous(), self.logit_scale_exp, logits, df)
+        if keep is not None:
+            keep.update(x2=X.view(B * T, D), df=df, P=P, T=T)
+        return logits, attn
+
+    def gradcam(self, X: torch.Tensor, text_features: torch.Tensor, mean_attn=None):
+        """Softmax-GradCAM of the last block w.r.t. its ln_1 output (pytorch_grad_cam/base_cam.py:62-118,
+        grad_cam.py:16-23) by explicit backward kernels.  X f32 [1,T,D] = output of encode_image_tokens.
+        Returns (cam [G,G] min-max scaled twice, logits [1,2])."""
+        keep: dict = {}
+        logits, _ = self._last_layer(X.clone(), text_features, mean_attn=mean_attn, keep=keep)
+        T, D, H = keep["T"], self.cfg.vision_width, self.cfg.vision_heads
+        dev = self.device
+        blk = self.vtower.blocks[-1]
+        Tp = _pad_to(T, 64)
+        f32 = dict(dtype=torch.float32, device=dev)
+        # ln_post backward: dy = df/(T-1) on patch rows, 0 on the class row
+        dx2 = torch.empty(T, D, **f32)
+        ops.layernorm_bwd(keep["x2"], self.ln_post.w, keep["df"], 0, 1.0 / (T - 1), 1, None, dx2, self.ln_post.eps)
+        # MLP backward
+        dh = torch.empty(T, 4 * D, **f32)
+        ops.linear(dx2, self.last_T["c_proj"], dh)                      # dh = dx2 @ W_proj
+        ops.quickgelu_bwd(dh, keep["pre"], dh)
+        dm = torch.empty(T, D, **f32)
+        ops.linear(dh, self.last_T["c_fc"], dm)                         # dm = dpre @ W_fc
+        dx1 = torch.empty(T, D, **f32)
+        ops.layernorm_bwd(keep["x1"], blk.ln2.w, dm, D, 1.0, 0, dx2, dx1, blk.ln2.eps)
+        # attention backward
+        do = torch.empty(T, D, **f32)
+        ops.linear(dx1, self.last_T["out_proj"], do)                    # dO = dx1 @ W_out
+        qkv, P = keep["qkv"], keep["P"]                                 # [T,3D], [H,T,Tp]
+        dP = torch.zeros(H, T, Tp, **f32)
+        ops.gemm(do, qkv, dP, T, T, 64, lda=D, ldb=3 * D, ldc=Tp, b_off=2 * D, nb0=1, nb1=H, sA=(0, 64), sB=(0, 64),
+                 sC=(0, T * Tp))                                        # dP = dO_h V_h^T
+        dS = torch.zeros(H, T, Tp, **f32)
+        ops.softmax_bwd(P, dP, dS, Tp, H, T, 0.125)                     # includes the 1/8 of q.k/8
+        dqkv = torch.zeros(T, 3 * D, **f32)
+        PT = torch.zeros(H, Tp, Tp, **f32)
+        ops.transpose_raw(P, 0, Tp, (0, T * Tp), PT, 0, Tp, (0, Tp * Tp), T, T, 1, H)
+        dOT = torch.zeros(H, 64, Tp, **f32)
+        ops.transpose_raw(do, 0, D, (0, 64), dOT, 0, Tp, (0, 64 * Tp), T, 64, 1, H)
+        # dV_h[key, d] = sum_q P[q,key] dO[q,d]
+        ops.gemm(PT, dOT, dqkv, T, 64, Tp, lda=Tp, ldb=Tp, ldc=3 * D, c_off=2 * D, nb0=1, nb1=H, sA=(0, Tp * Tp),
+                 sB=(0, 64 * Tp), sC=(0, 64))
+        KT_ = torch.zeros(H, 64, Tp, **f32)
+        ops.transpose_raw(qkv, D, 3 * D, (0, 64), KT_, 0, Tp, (0, 64 * Tp), T, 64, 1, H)
+        # dQ_h = dS_h K_h
+        ops.gemm(dS, KT_, dqkv, T, 64, Tp, lda=Tp, ldb=Tp, ldc=3 * D, c_off=0, nb0=1, nb1=H, sA=(0, T * Tp),
+                 sB=(0, 64 * Tp), sC=(0, 64))
+        dST = torch.zeros(H, Tp, Tp, **f32)
+        ops.transpose_raw(dS, 0, Tp, (0, T * Tp), dST, 0, Tp, (0, Tp * Tp), T, T, 1, H)
+        QT = torch.zeros(H, 64, Tp, **f32)
+        ops.transpose_raw(qkv, 0, 3 * D, (0, 64), QT, 0, Tp, (0, 64 * Tp), T, 64, 1, H)
+        # dK_h = dS_h^T Q_h
+        ops.gemm(dST, QT, dqkv, T, 64, Tp, lda=Tp, ldb=Tp, ldc=3 * D, c_off=D, nb0=1, nb1=H, sA=(0, Tp * Tp),
+                 sB=(0, 64 * Tp), sC=(0, 64))
+        grad = torch.empty(T, D, **f32)
+        ops.linear(dqkv, self.last_T["in_proj"], grad)                  # d ln1 = dqkv @ W_in
+        # channel weights = mean gradient over the patch tokens; cam = relu(sum_c w_c act_c)
+        wgt = torch.empty(D, **f32)
+        ops.col_mean(grad, 1, T, wgt)
+        cam = torch.empty(T - 1, **f32)
+        ops.cam_rows(keep["ln1"], wgt, 1, T - 1, cam)
+        ops.minmax(cam, cam)
+        ops.minmax(cam, cam)
+        g = int(math.isqrt(T - 1))
+        return cam.view(g, g), logits, grad
+
+
+class AlphaCLIP(_TextTower):
+    def __init__(self, cfg: ClipCfg, sd: SD, device="cuda", dtype=torch.float32):
+        device = torch.device(device)
+        super().__init__(cfg, sd, device, dtype)
+        W, p = cfg.vision_width, cfg.vision_patch_size
+        self.vtower = Tower(W, cfg.vision_heads, device, dtype)
+        for i in range(cfg.vision_layers):
+            pre = f"visual.transformer.resblocks.{i}"
+            names = dict(ln1=pre + ".ln_1", ln2=pre + ".ln_2", qkv_w=pre + ".attn.in_proj.weight", qkv_b=pre + ".attn.in_proj.bias",
+                         proj=pre + ".attn.out_proj", fc1=pre + ".mlp.c_fc", fc2=pre + ".mlp.c_proj")
+            self.vtower.blocks.append(_make_block(sd, names, W, device, dtype, 1e-5, ACT_QUICKGELU))
+        # RGB and alpha patch embeddings share one GEMM: K = 3*p*p (image) + p*p (alpha)
+        w_rgba = torch.cat([sd["visual.conv1.weight"].reshape(W, 3 * p * p), sd["visual.conv1_alpha.weight"].reshape(W, p * p)], dim=1)
+        self.conv_rgb = Lin(sd["visual.conv1.weight"].reshape(W, 3 * p * p), None, dtype, device)
+        self.conv_alpha = Lin(sd["visual.conv1_alpha.weight"].reshape(W, p * p), None, dtype, device)
+        self.conv_rgba = Lin(w_rgba, None, dtype, device)
+        self.class_embedding = sd["visual.class_embedding"].float().to(device)
+        self.pos = sd["visual.positional_embedding"].float().to(device).contiguous()
+        self.ln_pre = Norm(sd, "visual.ln_pre", device, 1e-5)
+        self.ln_post = Norm(sd, "visual.ln_post", device, 1e-5)
+        self.vproj_t = Lin(sd["visual.proj"].t().contiguous(), None, torch.float32, device)  # [E, W]
+        self._bufs: Dict[int, dict] = {}
+        self.input_resolution = cfg.image_resolution
+
+    def visual(self, image: torch.Tensor, alpha: torch.Tensor, image_u8: bool = False, mean=None, std=None) -> torch.Tensor:
+        """model.visual(image, alpha) (alpha_clip/model.py:358-386).  ``image`` is [n,3,R,R] or [1,3,R,R]
+        (one image shared by all alpha planes: its patch embedding is computed once and broadcast)."""
+        cfg = self.cfg
+        n = alpha.shape[0]
+        p, D, R = cfg.vision_patch_size, cfg.vision_width, cfg.image_resolution
+        g = R // p
+        Pn, T = g * g, g * g + 1
+        assert alpha.shape[1:] == (1, R, R) and image.shape[1:] == (3, R, R) and image.shape[0] in (1, n)
+        b = self._bufs.get(n)
+        if b is None:
+            b = self._bufs[n] = dict(
+                cols_a=torch.zeros(n * Pn, self.conv_alpha.Kp, dtype=self.dtype, device=self.device),
+                cols_rgb={},
+                rgb=torch.zeros(Pn, D, dtype=torch.float32, device=self.device),
+                cls=torch.zeros(n, D, dtype=torch.float32, device=self.device),
+                feat=torch.zeros(n, cfg.embed_dim, dtype=torch.float32, device=self.device),
+            )
+        X = torch.empty(n, T, D, dtype=torch.float32, device=self.device)
+        shared = image.shape[0] == 1
+        nb_img = image.shape[0]
+        cols_rgb = b["cols_rgb"].get(nb_img)
+        if cols_rgb is None:
+            cols_rgb = b["cols_rgb"][nb_img] = torch.zeros(nb_img * Pn, self.conv_rgb.Kp, dtype=self.dtype, device=self.device)
+        img = image.contiguous() if image.dtype == torch.uint8 else image.contiguous().float()
+        ops.im2col(img, p, cols_rgb, mean=mean, std=std, prescale=(1.0 / 255.0) if image.dtype == torch.uint8 else 1.0)
+        alpha_f = alpha.contiguous().float() if alpha.dtype != torch.float32 else alpha.contiguous()
+        ops.im2col(alpha_f, p, b["cols_a"])
+        if shared:
+            # rgb[Pn, D] = conv1(image) + pos[1:], then X[b, 1+i] = conv1_alpha(alpha_b)[i] + rgb[i]
+            ops.gemm(cols_rgb, self.conv_rgb.w, b["rgb"], Pn, D, self.conv_rgb.Kp, lda=self.conv_rgb.Kp, ldb=self.conv_rgb.Kp,
+                     ldc=D, residual=self.pos, r_off=D, ldr=D)
+            ops.gemm(b["cols_a"], self.conv_alpha.w, X, Pn, D, self.conv_alpha.Kp, lda=self.conv_alpha.Kp, ldb=self.conv_alpha.Kp,
+                     ldc=D, c_off=D, nb0=n, sA=(Pn * self.conv_alpha.Kp, 0), sC=(T * D, 0), residual=b["rgb"], ldr=D)
+        else:
+            ops.gemm(cols_rgb, self.conv_rgb.w, X, Pn, D, self.conv_rgb.Kp, lda=self.conv_rgb.Kp, ldb=self.conv_rgb.Kp, ldc=D,
+                     c_off=D, nb0=n, sA=(Pn * self.conv_rgb.Kp, 0), sC=(T * D, 0), residual=self.pos, r_off=D, ldr=D)
+            ops.gemm(b["cols_a"], self.conv_alpha.w, X, Pn, D, self.conv_alpha.Kp, lda=self.conv_alpha.Kp, ldb=self.conv_alpha.Kp,
+                     ldc=D, c_off=D, nb0=n, sA=(Pn * self.conv_alpha.Kp, 0), sC=(T * D, 0), residual=X, r_off=D, ldr=D,
+                     sR=(T * D, 0))
+        ops.write_prefix_tokens(X, self.class_embedding, self.pos[0], None)
+        X2 = X.view(n * T, D)
+        ops.layernorm(X2, self.ln_pre.w, self.ln_pre.b, X2, self.ln_pre.eps)
+        for blk in self.vtower.blocks:
+            self.vtower.block_forward(X, blk)
+        cls_rows = X[:, 0, :]                                    # view with row stride T*D
+        ops.layernorm(cls_rows, self.ln_post.w, self.ln_post.b, b["cls"], self.ln_post.eps)
+        ops.linear(b["cls"], self.vproj_t.w, b["feat"])
+        return b["feat"]

@@ -1,0 +1,424 @@
+"""Tensor-level wrappers over the C-ABI.
+
+Every function validates shapes and extents on the host (a kernel that reads out of
+bounds can take the whole GPU down), then passes raw device pointers and the current
+HIP stream to ``libmars_hip.so``.  Nothing here computes with torch.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import hip
+from .hip import BF16, F32, MarsGemm
+
+_vp = ctypes.c_void_p
+
+# When bench.py sets GEMM_PROFILE to a list, every GEMM launch of dtype GEMM_PROFILE_DTYPE is
+# bracketed by timing events and (start, end, flops) is appended.
+GEMM_PROFILE = None
+GEMM_PROFILE_DTYPE = BF16
+
+
+def stream() -> _vp:
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor], byte_offset: int = 0) -> Optional[_vp]:
+    if t is None:
+        return None
+    return _vp(t.data_ptr() + byte_offset)
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _req(cond: bool, msg: str):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None:
+            _req(t.is_cuda, "tensor must live on the GPU")
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
+         a_off: int = 0, b_off: int = 0, c_off: int = 0, nb0: int = 1, nb1: int = 1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), bias: Optional[torch.Tensor] = None,
+         gamma: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, r_off: int = 0, ldr: int = 0,
+         sR=(0, 0), alpha: float = 1.0, act: int = 0):
+    """C[M,N] (+batches) = epilogue(A[M,K] . B[N,K]^T).  Offsets and strides are in elements."""
+    _dev(A, B, C, bias, gamma, residual)
+    _req(A.dtype == B.dtype, "A and B must share a dtype")
+    _req(M > 0 and N > 0 and K > 0, "empty gemm")
+    ea = A.element_size()
+    _req((K * ea) % 128 == 0, f"K={K} must span a multiple of 128 bytes")
+    # extent checks: last element touched by each operand
+    last_a = a_off + (nb0 - 1) * sA[0] + (nb1 - 1) * sA[1] + (M - 1) * lda + K
+    last_b = b_off + (nb0 - 1) * sB[0] + (nb1 - 1) * sB[1] + (N - 1) * ldb + K
+    last_c = c_off + (nb0 - 1) * sC[0] + (nb1 - 1) * sC[1] + (M - 1) * ldc + N
+    _req(last_a <= _avail(A), f"gemm A overruns its buffer ({last_a} > {_avail(A)})")
+    _req(last_b <= _avail(B), f"gemm B overruns its buffer ({last_b} > {_avail(B)})")
+    _req(last_c <= _avail(C), f"gemm C overruns its buffer ({last_c} > {_avail(C)})")
+    if bias is not None:
+        _req(bias.dtype == torch.float32 and bias.numel() >= N, "bias must be f32 [N]")
+    if gamma is not None:
+        _req(gamma.dtype == torch.float32 and gamma.numel() >= N, "gamma must be f32 [N]")
+    if residual is not None:
+        _req(residual.dtype == torch.float32, "residual must be f32")
+        last_r = r_off + (nb0 - 1) * sR[0] + (nb1 - 1) * sR[1] + (M - 1) * ldr + N
+        _req(last_r <= _avail(residual), "gemm residual overruns its buffer")
+    g = MarsGemm()
+    g.A, g.B, g.C = A.data_ptr() + a_off * ea, B.data_ptr() + b_off * ea, C.data_ptr() + c_off * C.element_size()
+    g.lda, g.ldb, g.ldc = lda, ldb, ldc
+    g.sA0, g.sA1, g.sB0, g.sB1, g.sC0, g.sC1 = sA[0], sA[1], sB[0], sB[1], sC[0], sC[1]
+    g.M, g.N, g.K, g.nb0, g.nb1 = M, N, K, nb0, nb1
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.gamma = gamma.data_ptr() if gamma is not None else None
+    g.residual = residual.data_ptr() + r_off * 4 if residual is not None else None
+    g.ldr, g.sR0, g.sR1 = ldr, sR[0], sR[1]
+    g.alpha, g.act, g.in_dtype, g.out_dtype = alpha, act, dt(A), dt(C)
+    if GEMM_PROFILE is not None and dt(A) == GEMM_PROFILE_DTYPE:
+        # bench.py: time this launch with events on the stream it runs on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.check(hip.lib().marship_gemm(ctypes.byref(g), stream()), "marship_gemm")
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * nb0 * nb1))
+        return
+    hip.check(hip.lib().marship_gemm(ctypes.byref(g), stream()), "marship_gemm")
+
+
+def _avail(t: torch.Tensor) -> int:
+    """elements available from t's first element to the end of its storage"""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = 0, gamma=None,
+           residual: Optional[torch.Tensor] = None, alpha: float = 1.0):
+    """out[M,N] = epilogue(x[M,K] . w[N,K]^T) for row-major 2-D views (last dim contiguous)."""
+    _req(x.dim() == 2 and w.dim() == 2 and out.dim() == 2, "linear expects 2-D tensors")
+    _req(x.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1, "last dim must be contiguous")
+    M, K = x.shape
+    N = w.shape[0]
+    _req(w.shape[1] == K and out.shape[0] == M and out.shape[1] == N, f"linear shape mismatch {x.shape} {w.shape} {out.shape}")
+    if residual is not None:
+        _req(residual.dim() == 2 and residual.shape[0] == M and residual.shape[1] == N and residual.stride(1) == 1,
+             "residual shape mismatch")
+    gemm(x, w, out, M, N, K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, gamma=gamma,
+         residual=residual, ldr=residual.stride(0) if residual is not None else 0, alpha=alpha, act=act)
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float):
+    _dev(x, w, b, out)
+    _req(x.dtype == torch.float32 and x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1, "layernorm: bad x/out")
+    rows, D = x.shape
+    _req(out.shape[0] == rows and out.shape[1] == D and w.numel() == D and b.numel() == D, "layernorm: shape mismatch")
+    _req((rows - 1) * x.stride(0) + D <= _avail(x) and (rows - 1) * out.stride(0) + D <= _avail(out), "layernorm: overrun")
+    hip.check(hip.lib().marship_layernorm(ptr(x), x.stride(0), ptr(w), ptr(b), ptr(out), out.stride(0), rows, D, eps,
+                                          dt(out), stream()), "marship_layernorm")
+
+
+def im2col(img: torch.Tensor, p: int, out: torch.Tensor, *, mean=None, std=None, prescale: float = 1.0, col_off: int = 0):
+    _dev(img, out, mean, std)
+    _req(img.dim() == 4 and img.is_contiguous(), "im2col: image must be contiguous [B,C,H,W]")
+    _req(img.dtype in (torch.float32, torch.uint8), "im2col: image must be f32 or u8")
+    B, C, H, W = img.shape
+    _req(out.dim() == 2 and out.stride(1) == 1 and out.shape[0] == B * (H // p) * (W // p), "im2col: bad out rows")
+    _req(out.shape[1] >= C * p * p + col_off, "im2col: out too narrow")
+    if mean is not None:
+        _req(mean.numel() == C and std.numel() == C and mean.dtype == torch.float32, "im2col: mean/std size")
+    hip.check(hip.lib().marship_im2col(ptr(img), 1 if img.dtype == torch.uint8 else 0, B, C, H, W, p, ptr(mean), ptr(std),
+                                       prescale, ptr(out), out.stride(0), col_off, dt(out), stream()), "marship_im2col")
+
+
+def write_prefix_tokens(X: torch.Tensor, cls: torch.Tensor, pos0: Optional[torch.Tensor], regs: Optional[torch.Tensor]):
+    _dev(X, cls, pos0, regs)
+    _req(X.dim() == 3 and X.is_contiguous() and X.dtype == torch.float32, "prefix tokens: X must be contiguous f32 [B,T,D]")
+    B, T, D = X.shape
+    nr = 0 if regs is None else regs.numel() // D
+    _req(cls.numel() == D and (pos0 is None or pos0.numel() >= D), "prefix tokens: cls/pos size")
+    hip.check(hip.lib().marship_write_prefix_tokens(ptr(X), B, T, D, ptr(cls), ptr(pos0), ptr(regs), nr, stream()),
+              "marship_write_prefix_tokens")
+
+
+def transpose_raw(src: torch.Tensor, s_off: int, ldi: int, sI, dst: torch.Tensor, d_off: int, ldo: int, sO, rows: int,
+                  cols: int, nb0: int, nb1: int):
+    _dev(src, dst)
+    _req(src.element_size() == dst.element_size() and src.element_size() in (2, 4), "transpose: element size")
+    last_i = s_off + (nb0 - 1) * sI[0] + (nb1 - 1) * sI[1] + (rows - 1) * ldi + cols
+    last_o = d_off + (nb0 - 1) * sO[0] + (nb1 - 1) * sO[1] + (cols - 1) * ldo + rows
+    _req(last_i <= _avail(src) and last_o <= _avail(dst), "transpose: overrun")
+    es = src.element_size()
+    hip.check(hip.lib().marship_transpose(ptr(src, s_off * es), ldi, sI[0], sI[1], ptr(dst, d_off * es), ldo, sO[0], sO[1],
+                                          rows, cols, nb0, nb1, es, stream()), "marship_transpose")
+
+
+def softmax_rows(S: torch.Tensor, P: torch.Tensor, nb: int, T: int, ld: int, causal: bool):
+    _dev(S, P)
+    _req(S.dtype == torch.float32 and nb * T * ld <= _avail(S) and nb * T * ld <= _avail(P), "softmax_rows: overrun")
+    hip.check(hip.lib().marship_softmax_rows(ptr(S), ld, ptr(P), ld, nb, T, 1 if causal else 0, dt(P), stream()),
+              "marship_softmax_rows")
+
+
+def attn_mean_accum(P: torch.Tensor, p_off: int, ldp: int, head_stride: int, H: int, off: int, Pn: int, scale: float,
+                    acc: torch.Tensor):
+    _dev(P, acc)
+    _req(acc.dtype == torch.float32 and acc.dim() == 2 and acc.stride(1) == 1 and acc.shape[0] >= Pn and acc.shape[1] >= Pn,
+         "attn_mean_accum: bad accumulator")
+    _req(p_off + (H - 1) * head_stride + (off + Pn - 1) * ldp + off + Pn <= _avail(P), "attn_mean_accum: overrun")
+    hip.check(hip.lib().marship_attn_mean_accum(ptr(P, p_off * P.element_size()), ldp, head_stride, H, off, Pn, scale,
+                                                ptr(acc), acc.stride(0), dt(P), stream()), "marship_attn_mean_accum")
+
+
+def swiglu(x12: torch.Tensor, out: torch.Tensor):
+    _dev(x12, out)
+    _req(x12.dim() == 2 and x12.is_contiguous() and out.dim() == 2 and out.stride(1) == 1 and x12.dtype == out.dtype, "swiglu: layout")
+    M, H2 = x12.shape
+    _req(out.shape[0] == M and out.shape[1] >= H2 // 2, "swiglu: shape")
+    hip.check(hip.lib().marship_swiglu(ptr(x12), ptr(out), out.stride(0), M, H2 // 2, dt(out), stream()), "marship_swiglu")
+
+
+def cast(src: torch.Tensor, dst: torch.Tensor):
+    _dev(src, dst)
+    _req(src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel(), "cast: layout")
+    hip.check(hip.lib().marship_cast(ptr(src), ptr(dst), src.numel(), dt(src), dt(dst), stream()), "marship_cast")
+
+
+def flash_attn(qkv: torch.Tensor, O: torch.Tensor, lse: Optional[torch.Tensor], B: int, T: int, H: int, causal: bool):
+    _dev(qkv, O, lse)
+    D = H * 64
+    _req(qkv.dtype == torch.bfloat16 and O.dtype == torch.bfloat16, "flash_attn: bf16 only")
+    _req(B * T * 3 * D <= _avail(qkv) and B * T * D <= _avail(O), "flash_attn: overrun")
+    if lse is not None:
+        _req(lse.dtype == torch.float32 and B * H * T <= _avail(lse), "flash_attn: lse overrun")
+    hip.check(hip.lib().marship_flash_attn(ptr(qkv), ptr(O), ptr(lse), B, T, H, 1 if causal else 0, stream()),
+              "marship_flash_attn")
+
+
+def flash_attn_mean(qkv: torch.Tensor, lse: torch.Tensor, T: int, H: int, off: int, Pn: int, scale: float,
+                    acc: torch.Tensor):
+    _dev(qkv, lse, acc)
+    _req(qkv.dtype == torch.bfloat16 and T * 3 * H * 64 <= _avail(qkv) and H * T <= _avail(lse), "flash_attn_mean: overrun")
+    _req(acc.dtype == torch.float32 and acc.dim() == 2 and acc.stride(1) == 1 and acc.shape[0] >= Pn and acc.shape[1] >= Pn,
+         "flash_attn_mean: bad accumulator")
+    hip.check(hip.lib().marship_flash_attn_mean(ptr(qkv), ptr(lse), T, H, off, Pn, scale, ptr(acc), acc.stride(0), stream()),
+              "marship_flash_attn_mean")
+
+
+def l2norm_rows(x: torch.Tensor, row_off: int, rows: int, out: torch.Tensor):
+    """x f32 [B,T,D] -> out [B*rows, D]: rows row_off.. of every image, unit length."""
+    _dev(x, out)
+    _req(x.dim() == 3 and x.is_contiguous() and x.dtype == torch.float32, "l2norm_rows: x must be contiguous f32 [B,T,D]")
+    B, T, D = x.shape
+    _req(row_off + rows <= T and out.dim() == 2 and out.shape[0] == B * rows and out.shape[1] >= D and out.stride(1) == 1,
+         "l2norm_rows: shape")
+    hip.check(hip.lib().marship_l2norm_rows(ptr(x), T * D, D, row_off, B, rows, D, ptr(out), out.stride(0), dt(out), stream()),
+              "marship_l2norm_rows")
+
+
+def vva_prior(S: torch.Tensor, fg: torch.Tensor, P: int, ws: torch.Tensor, chunks: int, out: torch.Tensor):
+    _dev(S, fg, ws, out)
+    R = S.shape[0]
+    _req(S.dtype == torch.float32 and S.dim() == 2 and S.stride(1) == 1 and S.shape[1] >= P, "vva_prior: S layout")
+    _req(fg.dtype == torch.uint8 and fg.numel() == R and ws.numel() >= 4 * chunks * P and out.numel() >= P, "vva_prior: sizes")
+    hip.check(hip.lib().marship_vva_prior(ptr(S), S.stride(0), ptr(fg), R, P, ptr(ws), chunks, ptr(out), stream()),
+              "marship_vva_prior")
+
+
+def minmax(x: torch.Tensor, y: torch.Tensor):
+    _dev(x, y)
+    _req(x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and y.numel() == x.numel(), "minmax: layout")
+    hip.check(hip.lib().marship_minmax(ptr(x), ptr(y), x.numel(), stream()), "marship_minmax")
+
+
+def box_mask(prior: torch.Tensor, threshold: float, out: torch.Tensor):
+    _dev(prior, out)
+    G = prior.shape[0]
+    _req(prior.dim() == 2 and prior.shape[1] == G and prior.is_contiguous() and prior.dtype == torch.float32, "box_mask: prior")
+    _req(out.numel() == G * G and out.dtype == torch.float32, "box_mask: out")
+    hip.check(hip.lib().marship_box_mask(ptr(prior), G, float(threshold), ptr(out), stream()), "marship_box_mask")
+
+
+def sinkhorn1(A: torch.Tensor, D: torch.Tensor, P: int, scratch: torch.Tensor):
+    _dev(A, D, scratch)
+    _req(A.dtype == torch.float32 and A.dim() == 2 and A.stride(1) == 1 and A.shape[0] >= P and A.shape[1] >= P, "sinkhorn1: A")
+    _req(D.dim() == 2 and D.stride(1) == 1 and D.shape[0] >= P and D.stride(0) == D.shape[1], "sinkhorn1: D")
+    _req(scratch.numel() >= 33 * P, "sinkhorn1: scratch needs 33*P floats")
+    hip.check(hip.lib().marship_sinkhorn1(ptr(A), A.stride(0), ptr(D), D.stride(0), P, ptr(scratch), stream()),
+              "marship_sinkhorn1")
+
+
+def max_and_transpose(D: torch.Tensor, DDT: torch.Tensor, P: int, R: torch.Tensor, RT: torch.Tensor):
+    _dev(D, DDT, R, RT)
+    ld = D.stride(0)
+    for t in (D, DDT, R, RT):
+        _req(t.dtype == torch.float32 and t.dim() == 2 and t.stride(0) == ld and t.shape[0] >= P and t.shape[1] == ld,
+             "max_and_transpose: all four matrices must be [>=P, ld]")
+    hip.check(hip.lib().marship_max_and_transpose(ptr(D), ptr(DDT), ld, P, ptr(R), ptr(RT), stream()),
+              "marship_max_and_transpose")
+
+
+def masked_matvec(R2: torch.Tensor, Bm: torch.Tensor, prior: torch.Tensor, P: int, out: torch.Tensor):
+    _dev(R2, Bm, prior, out)
+    _req(R2.dim() == 2 and R2.shape[0] >= P and R2.shape[1] >= P and Bm.numel() >= P and prior.numel() >= P and out.numel() >= P,
+         "masked_matvec: sizes")
+    hip.check(hip.lib().marship_masked_matvec(ptr(R2), R2.stride(0), ptr(Bm), ptr(prior), P, ptr(out), stream()),
+              "marship_masked_matvec")
+
+
+def resample_axis(src: torch.Tensor, planes: int, H: int, W: int, axis: int, table, dst: torch.Tensor, *,
+                  quant_u8: bool = False, shift: float = 0.0, scale: float = 1.0):
+    """table = (xmin i32 [nout], xsize i32 [nout], weights f32 [nout, kmax]) on the device."""
+    xmin, xsize, wts = table
+    _dev(src, dst, xmin, xsize, wts)
+    nout, kmax = wts.shape
+    _req(src.dtype == torch.float32 and planes * H * W <= _avail(src), "resample_axis: src overrun")
+    total = planes * (nout if axis == 0 else H) * (nout if axis == 1 else W)
+    _req(total <= _avail(dst), "resample_axis: dst overrun")
+    hip.check(hip.lib().marship_resample_axis(ptr(src), planes, H, W, axis, nout, ptr(xmin), ptr(xsize), ptr(wts), kmax,
+                                              1 if quant_u8 else 0, shift, scale, ptr(dst), dt(dst), stream()),
+              "marship_resample_axis")
+
+
+def resample_axis_u8(src: torch.Tensor, planes: int, H: int, W: int, axis: int, table, dst: torch.Tensor):
+    xmin, xsize, kk = table
+    _dev(src, dst, xmin, xsize, kk)
+    nout, kmax = kk.shape
+    _req(src.dtype == torch.uint8 and dst.dtype == torch.uint8 and planes * H * W <= _avail(src), "resample_axis_u8: src")
+    total = planes * (nout if axis == 0 else H) * (nout if axis == 1 else W)
+    _req(total <= _avail(dst), "resample_axis_u8: dst overrun")
+    hip.check(hip.lib().marship_resample_axis_u8(ptr(src), planes, H, W, axis, nout, ptr(xmin), ptr(xsize), ptr(kk), kmax,
+                                                 ptr(dst), stream()), "marship_resample_axis_u8")
+
+
+def f32_to_u8(src: torch.Tensor, dst: torch.Tensor):
+    _dev(src, dst)
+    _req(src.dtype == torch.float32 and dst.dtype == torch.uint8 and src.is_contiguous() and dst.numel() == src.numel(), "f32_to_u8")
+    hip.check(hip.lib().marship_f32_to_u8(ptr(src), ptr(dst), src.numel(), stream()), "marship_f32_to_u8")
+
+
+def pool_masks(masks: torch.Tensor, G: int, bits: torch.Tensor):
+    _dev(masks, bits)
+    _req(masks.dim() == 3 and masks.is_contiguous() and masks.dtype == torch.float32 and masks.shape[1] == masks.shape[2],
+         "pool_masks: masks must be contiguous f32 [N,S,S]")
+    N, S, _ = masks.shape
+    _req(bits.dtype == torch.uint8 and bits.numel() >= N * G * G, "pool_masks: bits")
+    hip.check(hip.lib().marship_pool_masks(ptr(masks), N, S, G, ptr(bits), stream()), "marship_pool_masks")
+
+
+def proposal_stats(bits, N, P, vva, vta, cnt, svv, svt, ucnt):
+    _dev(bits, vva, vta, cnt, svv, svt, ucnt)
+    _req(bits.numel() >= N * P and vva.numel() >= P and vta.numel() >= P and cnt.numel() >= N and svv.numel() >= N and svt.numel() >= N,
+         "proposal_stats: sizes")
+    _req(cnt.dtype == torch.int32 and ucnt.dtype == torch.int32 and vva.dtype == torch.float32 and vta.dtype == torch.float32,
+         "proposal_stats: dtypes")
+    hip.check(hip.lib().marship_proposal_stats(ptr(bits), N, P, ptr(vva), ptr(vta), ptr(cnt), ptr(svv), ptr(svt), ptr(ucnt),
+                                               stream()), "marship_proposal_stats")
+
+
+def cosine_scores(feats: torch.Tensor, text: torch.Tensor, scores: torch.Tensor):
+    _dev(feats, text, scores)
+    _req(feats.dim() == 2 and feats.stride(1) == 1 and feats.dtype == torch.float32 and text.dtype == torch.float32, "cosine_scores")
+    N, E = feats.shape
+    _req(text.numel() >= E and scores.numel() >= N, "cosine_scores: sizes")
+    hip.check(hip.lib().marship_cosine_scores(ptr(feats), feats.stride(0), N, E, ptr(text), ptr(scores), stream()),
+              "marship_cosine_scores")
+
+
+def rank(emd, aclip, cnt, svv, svt, ucnt, N, alpha, sthr, dthr, score, order, keep):
+    _dev(emd, aclip, cnt, svv, svt, ucnt, score, order, keep)
+    _req(emd.dtype == torch.float64 and score.dtype == torch.float64 and order.dtype == torch.int32 and keep.dtype == torch.uint8,
+         "rank: dtypes")
+    for t in (emd, aclip, cnt, svv, svt, score, order, keep):
+        _req(t.numel() >= N, "rank: sizes")
+    hip.check(hip.lib().marship_rank(ptr(emd), ptr(aclip), ptr(cnt), ptr(svv), ptr(svt), ptr(ucnt), N, alpha, sthr, dthr,
+                                     ptr(score), ptr(order), ptr(keep), stream()), "marship_rank")
+
+
+def merge_masks(masks: torch.Tensor, keep: torch.Tensor, merged: torch.Tensor):
+    _dev(masks, keep, merged)
+    _req(masks.is_contiguous() and masks.dtype == torch.float32 and merged.dtype == torch.float32, "merge_masks")
+    N = masks.shape[0]
+    HW = masks.numel() // N
+    _req(merged.numel() == HW and keep.numel() >= N, "merge_masks: sizes")
+    hip.check(hip.lib().marship_merge_masks(ptr(masks), ptr(keep), N, HW, ptr(merged), stream()), "marship_merge_masks")
+
+
+def iou_counts(pred: torch.Tensor, gt: torch.Tensor, ignore: Optional[torch.Tensor], counts: torch.Tensor):
+    _dev(pred, gt, ignore, counts)
+    _req(pred.is_contiguous() and gt.is_contiguous() and pred.numel() == gt.numel() and pred.dtype == torch.float32 and gt.dtype == torch.float32,
+         "iou_counts: layout")
+    _req(counts.dtype == torch.float32 and counts.numel() >= 4, "iou_counts: counts")
+    if ignore is not None:
+        _req(ignore.is_contiguous() and ignore.numel() == pred.numel() and ignore.dtype == torch.float32, "iou_counts: ignore")
+    hip.check(hip.lib().marship_iou_counts(ptr(pred), ptr(gt), ptr(ignore), pred.numel(), ptr(counts), stream()),
+              "marship_iou_counts")
+
+
+def layernorm_bwd(x, w, dy, dy_stride, dy_scale, skip_rows, add, dx, eps):
+    _dev(x, w, dy, add, dx)
+    _req(x.dim() == 2 and x.is_contiguous() and dx.is_contiguous() and dx.shape == x.shape and x.dtype == torch.float32, "ln_bwd")
+    rows, D = x.shape
+    _req(w.numel() == D and (rows - 1) * dy_stride + D <= _avail(dy), "ln_bwd: sizes")
+    if add is not None:
+        _req(add.is_contiguous() and add.shape == x.shape, "ln_bwd: add")
+    hip.check(hip.lib().marship_layernorm_bwd(ptr(x), ptr(w), ptr(dy), dy_stride, dy_scale, skip_rows, ptr(add), ptr(dx),
+                                              rows, D, eps, stream()), "marship_layernorm_bwd")
+
+
+def quickgelu_bwd(dh, pre, out):
+    _dev(dh, pre, out)
+    _req(dh.is_contiguous() and pre.is_contiguous() and out.is_contiguous() and dh.numel() == pre.numel() == out.numel(), "qg_bwd")
+    hip.check(hip.lib().marship_quickgelu_bwd(ptr(dh), ptr(pre), ptr(out), dh.numel(), stream()), "marship_quickgelu_bwd")
+
+
+def softmax_bwd(P, dP, dS, ld, nb, T, scale):
+    _dev(P, dP, dS)
+    _req(nb * T * ld <= min(_avail(P), _avail(dP), _avail(dS)) and P.dtype == torch.float32, "softmax_bwd: overrun")
+    hip.check(hip.lib().marship_softmax_bwd(ptr(P), ptr(dP), ptr(dS), ld, nb, T, scale, stream()), "marship_softmax_bwd")
+
+
+def col_mean(x, r0, r1, out):
+    _dev(x, out)
+    _req(x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and r1 <= x.shape[0] and out.numel() >= x.shape[1], "col_mean")
+    hip.check(hip.lib().marship_col_mean(ptr(x), x.stride(0), r0, r1, x.shape[1], ptr(out), stream()), "marship_col_mean")
+
+
+def cam_head(f, proj, text, ls_exp, logits, df):
+    _dev(f, proj, text, logits, df)
+    D, E = proj.shape
+    _req(proj.is_contiguous() and f.numel() >= D and text.numel() >= 2 * E and logits.numel() >= 2 and df.numel() >= D, "cam_head")
+    hip.check(hip.lib().marship_cam_head(ptr(f), ptr(proj), ptr(text), D, E, ls_exp, ptr(logits), ptr(df), stream()),
+              "marship_cam_head")
+
+
+def cam_rows(act, w, r0, rows, cam):
+    _dev(act, w, cam)
+    _req(act.dim() == 2 and act.stride(1) == 1 and r0 + rows <= act.shape[0] and w.numel() >= act.shape[1] and cam.numel() >= rows,
+         "cam_rows")
+    hip.check(hip.lib().marship_cam_rows(ptr(act), act.stride(0), ptr(w), r0, rows, act.shape[1], ptr(cam), stream()),
+              "marship_cam_rows")
+
+
+def emd_scores_host(S_host: torch.Tensor, fg_host: torch.Tensor, bits_host: torch.Tensor, threads: int = 0,
+                    is_cost: bool = False) -> torch.Tensor:
+    """Host routine: S f32 [R, ld] (CPU), fg u8 [R], bits u8 [N, P] -> f64 [N] scores 1 - emd."""
+    _req(not S_host.is_cuda and S_host.dtype == torch.float32 and S_host.dim() == 2 and S_host.stride(1) == 1, "emd: S must be CPU f32")
+    R = S_host.shape[0]
+    N, P = bits_host.shape
+    _req(S_host.shape[1] >= P and fg_host.numel() == R and fg_host.dtype == torch.uint8 and bits_host.dtype == torch.uint8
+         and bits_host.is_contiguous() and fg_host.is_contiguous(), "emd: sizes")
+    out = torch.empty(N, dtype=torch.float64)
+    hip.check(hip.lib().marshost_emd_scores(_vp(S_host.data_ptr()), S_host.stride(0), R, P, _vp(fg_host.data_ptr()),
+                                            _vp(bits_host.data_ptr()), N, 1 if is_cost else 0, _vp(out.data_ptr()), threads), "marshost_emd_scores")
+    return out

@@ -1,0 +1,437 @@
+"""Kernel-level parity on the GPU: every C-ABI entry point against a plain torch fp32 (or fp64)
+statement of the same arithmetic, at the odd shapes the pipeline produces."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (130, 70, 192), (1, 5, 64), (257, 384, 128), (81, 81, 128), (1374, 1024, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_plain(pkg, cuda, M, N, K, dtype):
+    a = _rand((M, K), 1, cuda).to(dtype)
+    b = _rand((N, K), 2, cuda).to(dtype)
+    out = torch.full((M, N), float("nan"), device=cuda)
+    pkg.ops.linear(a, b, out)
+    # bf16 operands are exact in the f32 products, so both types only differ from the f64
+    # reference by the f32 accumulation error
+    ref = a.double() @ b.double().t()
+    assert float((out.double() - ref).abs().max()) <= 1e-3
+
+
+def test_gemm_asymmetric_identity(pkg, cuda):
+    """A = I with an asymmetric B catches a swapped row/column map in the C write."""
+    K = 128
+    a = torch.eye(K, device=cuda)
+    b = torch.arange(96 * K, device=cuda, dtype=torch.float32).reshape(96, K) / 7.0
+    out = torch.zeros(K, 96, device=cuda)
+    pkg.ops.linear(a, b, out)
+    assert torch.equal(out, b.t().contiguous())
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_epilogue(pkg, cuda, act):
+    M, N, K = 77, 200, 128
+    a, b = _rand((M, K), 3, cuda), _rand((N, K), 4, cuda) * 0.2
+    bias, gamma = _rand((N,), 5, cuda), _rand((N,), 6, cuda)
+    res = _rand((M, N), 7, cuda)
+    out = res.clone()
+    pkg.ops.linear(a, b, out, bias=bias, gamma=gamma, residual=out, act=act, alpha=0.5)
+    z = 0.5 * (a @ b.t()) + bias
+    z = F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else z)
+    ref = res + gamma * z
+    assert float((out - ref).abs().max()) < 2e-4
+    outb = torch.zeros(M, N, device=cuda, dtype=torch.bfloat16)
+    pkg.ops.linear(a, b, outb, bias=bias, act=act)
+    z = (a @ b.t()) + bias
+    z = F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else z)
+    assert float((outb.float() - z).abs().max()) < 0.05
+
+
+def test_gemm_batched_strided(pkg, cuda):
+    """The attention-shaped call: per (image, head) views into a packed qkv buffer."""
+    B, H, T, D = 2, 3, 70, 192
+    Tp = 128
+    qkv = _rand((B * T, 3 * D), 8, cuda)
+    S = torch.zeros(B * H, T, Tp, device=cuda)
+    pkg.ops.gemm(qkv, qkv, S, T, T, 64, lda=3 * D, ldb=3 * D, ldc=Tp, a_off=0, b_off=D, nb0=B, nb1=H,
+                 sA=(T * 3 * D, 64), sB=(T * 3 * D, 64), sC=(H * T * Tp, T * Tp), alpha=0.125)
+    q = qkv.view(B, T, 3, H, 64)
+    ref = torch.einsum("bthd,bshd->bhts", q[:, :, 0], q[:, :, 1]) * 0.125
+    assert float((S.view(B, H, T, Tp)[..., :T] - ref).abs().max()) < 1e-4
+    assert float(S.view(B, H, T, Tp)[..., T:].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_shapes(pkg, cuda):
+    a, b, c = torch.zeros(4, 40, device=cuda), torch.zeros(4, 40, device=cuda), torch.zeros(4, 4, device=cuda)
+    with pytest.raises(ValueError):
+        pkg.ops.linear(a, b, c)                      # K not a 128-byte multiple
+    with pytest.raises(ValueError):
+        pkg.ops.gemm(torch.zeros(4, 64, device=cuda), torch.zeros(4, 64, device=cuda), c, 8, 4, 64, lda=64, ldb=64, ldc=4)
+
+
+# ------------------------------------------------------------------ ViT glue
+@pytest.mark.parametrize("D", [128, 384, 1024, 1536])
+def test_layernorm(pkg, cuda, D):
+    x = _rand((37, D), 1, cuda, 3.0) + 1.5
+    w, b = _rand((D,), 2, cuda), _rand((D,), 3, cuda)
+    y = torch.empty_like(x)
+    pkg.ops.layernorm(x, w, b, y, 1e-6)
+    assert float((y - F.layer_norm(x, (D,), w, b, 1e-6)).abs().max()) < 2e-5
+    yb = torch.empty(37, D, device=cuda, dtype=torch.bfloat16)
+    pkg.ops.layernorm(x, w, b, yb, 1e-5)
+    assert float((yb.float() - F.layer_norm(x, (D,), w, b, 1e-5)).abs().max()) < 0.05
+    # strided rows (class-token gather) and in-place
+    big = _rand((5, 7, D), 4, cuda)
+    rows = big[:, 0, :]
+    out = torch.empty(5, D, device=cuda)
+    pkg.ops.layernorm(rows, w, b, out, 1e-5)
+    assert float((out - F.layer_norm(rows, (D,), w, b, 1e-5)).abs().max()) < 2e-5
+    ref = F.layer_norm(x, (D,), w, b, 1e-5)
+    pkg.ops.layernorm(x, w, b, x, 1e-5)
+    assert float((x - ref).abs().max()) < 2e-5
+
+
+def test_im2col_matches_conv(pkg, cuda):
+    B, p, G, D = 2, 14, 5, 32
+    img = _rand((B, 3, p * G, p * G), 1, cuda)
+    wgt = _rand((D, 3, p, p), 2, cuda, 0.05)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=cuda)
+    std = torch.tensor([0.229, 0.224, 0.225], device=cuda)
+    Kp = 640
+    cols = torch.zeros(B * G * G, Kp, device=cuda)
+    pkg.ops.im2col(img, p, cols, mean=mean, std=std)
+    wp = torch.zeros(D, Kp, device=cuda)
+    wp[:, : 3 * p * p] = wgt.reshape(D, -1)
+    out = torch.empty(B * G * G, D, device=cuda)
+    pkg.ops.linear(cols, wp, out)
+    ref = F.conv2d((img - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1), wgt, stride=p).flatten(2).transpose(1, 2).reshape(-1, D)
+    assert float((out - ref).abs().max()) < 1e-4
+    # 8-bit input with the 1/255 prescale
+    u8 = (torch.rand(1, 3, 28, 28, device=cuda) * 255).to(torch.uint8)
+    cols8 = torch.zeros(4, Kp, device=cuda)
+    pkg.ops.im2col(u8, p, cols8, mean=mean, std=std, prescale=1.0 / 255.0)
+    ref8 = F.unfold((u8.float() / 255.0 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1), p, stride=p)[0].t()
+    assert float((cols8[:, : 3 * p * p] - ref8).abs().max()) < 1e-6
+
+
+def test_softmax_transpose_attnmean(pkg, cuda):
+    nb, T, ld = 5, 70, 128
+    S = _rand((nb, T, ld), 1, cuda, 3.0)
+    P = torch.full((nb, T, ld), float("nan"), device=cuda)
+    pkg.ops.softmax_rows(S, P, nb, T, ld, False)
+    assert float((P[..., :T] - S[..., :T].softmax(-1)).abs().max()) < 1e-6 and float(P[..., T:].abs().max()) == 0
+    pkg.ops.softmax_rows(S, P, nb, T, ld, True)
+    mask = torch.full((T, T), float("-inf"), device=cuda).triu_(1)
+    assert float((P[..., :T] - (S[..., :T] + mask).softmax(-1)).abs().max()) < 1e-6
+    Pb = torch.zeros(nb, T, ld, device=cuda, dtype=torch.bfloat16)
+    pkg.ops.softmax_rows(S, Pb, nb, T, ld, False)
+    assert float((Pb[..., :T].float() - S[..., :T].softmax(-1)).abs().max()) < 5e-3
+    # transpose, both element sizes
+    for dt in (torch.float32, torch.bfloat16):
+        x = _rand((3, 45, 70), 2, cuda).to(dt)
+        y = torch.zeros(3, 70, 64, device=cuda, dtype=dt)
+        pkg.ops.transpose_raw(x, 0, 70, (45 * 70, 0), y, 0, 64, (70 * 64, 0), 45, 70, 3, 1)
+        assert torch.equal(y[:, :, :45], x.transpose(1, 2)) and float(y[:, :, 45:].abs().max()) == 0
+    # head/layer mean accumulate
+    H, off, Pn = 4, 5, 60
+    probs = S[:H, :, :T].softmax(-1).contiguous()
+    acc = torch.zeros(Pn, 64, device=cuda)
+    pkg.ops.attn_mean_accum(probs, 0, T, T * T, H, off, Pn, 0.25, acc)
+    pkg.ops.attn_mean_accum(probs, 0, T, T * T, H, off, Pn, 0.25, acc)
+    assert float((acc[:, :Pn] - 2 * probs[:, off:off + Pn, off:off + Pn].mean(0)).abs().max()) < 1e-6
+
+
+def test_swiglu_cast_l2norm(pkg, cuda):
+    x = _rand((9, 2 * 344), 1, cuda)
+    out = torch.zeros(9, 384, device=cuda)
+    pkg.ops.swiglu(x, out)
+    ref = F.silu(x[:, :344]) * x[:, 344:]
+    assert float((out[:, :344] - ref).abs().max()) < 1e-6 and float(out[:, 344:].abs().max()) == 0
+    xb = torch.empty(9, 688, device=cuda, dtype=torch.bfloat16)
+    pkg.ops.cast(x, xb)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    X = _rand((2, 11, 192), 2, cuda)
+    y = torch.empty(2 * 6, 192, device=cuda)
+    pkg.ops.l2norm_rows(X, 5, 6, y)
+    assert float((y - F.normalize(X[:, 5:].reshape(-1, 192), dim=1)).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------ fused attention
+@pytest.mark.parametrize("B,T,H,causal", [(1, 64, 1, False), (2, 70, 2, False), (1, 577, 3, False), (3, 77, 2, True), (1, 1374, 2, False)])
+def test_flash_attention_matches_reference(pkg, cuda, B, T, H, causal):
+    D = H * 64
+    qkv = (_rand((B * T, 3 * D), 5, cuda) * 1.5).to(torch.bfloat16)
+    O = torch.full((B * T, D), float("nan"), device=cuda, dtype=torch.bfloat16)
+    lse = torch.zeros(B * H, T, device=cuda)
+    pkg.ops.flash_attn(qkv, O, lse, B, T, H, causal)
+    q = qkv.float().view(B, T, 3, H, 64)
+    s = torch.einsum("bthd,bshd->bhts", q[:, :, 0], q[:, :, 1]) * 0.125
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), device=cuda).triu_(1)
+    ref = torch.einsum("bhts,bshd->bthd", s.softmax(-1), q[:, :, 2]).reshape(B * T, D)
+    assert float((O.float() - ref).abs().max()) < 3e-2
+    assert float((lse.view(B, H, T) - torch.logsumexp(s, -1)).abs().max()) < 1e-3
+    if not causal:
+        off, Pn = 1, T - 1
+        ld = (Pn + 63) // 64 * 64
+        acc = torch.zeros(Pn, ld, device=cuda)
+        pkg.ops.flash_attn_mean(qkv, lse, T, H, off, Pn, 1.0 / H, acc)
+        want = s[0].softmax(-1)[:, off:, off:].mean(0)
+        assert float((acc[:, :Pn] - want).abs().max()) < 2e-3
+
+
+def test_flash_attention_spiked_scores(pkg, cuda):
+    """A key that dominates a row late in the sequence forces the online-softmax rescale."""
+    T, H = 200, 1
+    qkv = (_rand((T, 192), 9, cuda) * 0.5)
+    qkv[150, 64:128] = qkv[3, 0:64] * 40.0     # key 150 aligned with query 3
+    qkv = qkv.to(torch.bfloat16)
+    O = torch.zeros(T, 64, device=cuda, dtype=torch.bfloat16)
+    pkg.ops.flash_attn(qkv, O, None, 1, T, H, False)
+    q = qkv.float()
+    s = (q[:, 0:64] @ q[:, 64:128].t()) * 0.125
+    ref = s.softmax(-1) @ q[:, 128:192]
+    assert float((O.float() - ref).abs().max()) < 3e-2
+
+
+# ------------------------------------------------------------------ alignment / refinement
+def test_vva_prior_and_minmax(pkg, cuda):
+    R, P, ld = 162, 81, 128
+    S = _rand((R, ld), 1, cuda)
+    fg = (torch.rand(R, generator=torch.Generator().manual_seed(2)) < 0.3).to(torch.uint8).to(cuda)
+    out = torch.empty(P, device=cuda)
+    pkg.ops.vva_prior(S, fg, P, torch.zeros(4 * 32 * P, device=cuda), 32, out)
+    Sf, Sb = S[fg.bool(), :P], S[~fg.bool(), :P]
+    v = Sf.mean(0) * Sf.max(0).values - Sb.mean(0) * Sb.max(0).values
+    assert float((out - opipe.minmax(v)).abs().max()) < 1e-5
+    ones = torch.ones(R, dtype=torch.uint8, device=cuda)    # no background rows: foreground term only
+    pkg.ops.vva_prior(S, ones, P, torch.zeros(4 * 32 * P, device=cuda), 32, out)
+    v = S[:, :P].mean(0) * S[:, :P].max(0).values
+    assert float((out - opipe.minmax(v)).abs().max()) < 1e-5
+    x = _rand((1089,), 3, cuda)
+    y = torch.empty_like(x)
+    pkg.ops.minmax(x, y)
+    assert float((y - opipe.minmax(x)).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("G,thr", [(9, 0.8), (33, 0.4), (37, 0.8), (37, 0.4)])
+def test_box_mask_matches_oracle(pkg, cuda, G, thr):
+    from scipy import ndimage
+    rng = np.random.default_rng(G)
+    for trial in range(6):
+        prior = ndimage.uniform_filter(rng.random((G, G)).astype(np.float32), 3 + trial % 3)
+        prior = (prior - prior.min()) / (1e-7 + prior.max() - prior.min())
+        prior = ((np.floor(prior * 254) + 0.5) / 255).astype(np.float32)   # mid-bin values: trunc(x*255) is robust
+        want = opipe.box_mask(torch.from_numpy(prior.astype(np.float32)), thr)
+        got = torch.empty(G * G, device=cuda)
+        pkg.ops.box_mask(torch.from_numpy(prior.astype(np.float32)).to(cuda), thr, got)
+        assert torch.equal(got.view(G, G).cpu(), want)
+    got = torch.ones(G * G, device=cuda)
+    pkg.ops.box_mask(torch.zeros(G, G, device=cuda), thr, got)
+    assert float(got.sum()) == 0.0
+
+
+def test_refinement_chain_matches_oracle(pkg, cuda):
+    import importlib
+    PIR = importlib.import_module(pkg.__name__ + ".mars.components.PriorInformationRefinementModule")
+    for G, thr in ((9, 0.8), (33, 0.4)):
+        P = G * G
+        A = torch.rand(P, P, generator=torch.Generator().manual_seed(G)) ** 4 + 1e-3
+        A = A / A.sum(1, keepdim=True)
+        prior = opipe.minmax(torch.rand(G, G, generator=torch.Generator().manual_seed(G + 1)))
+        want = opipe.pir_refine(prior, A, thr)
+        mod = PIR.PriorInformationRefinementModule(thr, 8, cuda)
+        acc = mod.new_accumulator(P)
+        acc[:, :P].copy_(A.to(cuda))
+        got = mod.refine(prior.to(cuda), acc)
+        assert float((got.cpu() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+        # reference signature: list of per-block [1, h, T, T] maps with a class token
+        T = P + 1
+        maps = [torch.rand(1, 2, T, T, generator=torch.Generator().manual_seed(i)).softmax(-1) for i in range(3)]
+        want2 = opipe.pir_refine(prior, opipe.mean_attention(maps, 2, 0), thr)
+        mod2 = PIR.PriorInformationRefinementModule(thr, 2, cuda)
+        got2 = mod2.compute(prior.to(cuda), [m.to(cuda) for m in maps])
+        assert float((got2.cpu() - want2).abs().max()) < 1e-5 * max(1.0, float(want2.abs().max()))
+
+
+# ------------------------------------------------------------------ resampling
+def test_resample_kernels(pkg, cuda):
+    import importlib
+    from PIL import Image
+    rs = importlib.import_module(pkg.__name__ + ".resample")
+    dev = lambda t: tuple(torch.from_numpy(a).to(cuda).contiguous() for a in t)
+    g = torch.Generator().manual_seed(0)
+    for n_in, n_out, mode in [(126, 128, "bicubic"), (126, 56, "bilinear"), (518, 336, "bilinear"), (518, 528, "bicubic")]:
+        x = torch.rand(3, n_in, n_in, generator=g)
+        ref = F.interpolate(x[None], size=(n_out, n_out), mode=mode, align_corners=False, antialias=True)[0]
+        tab = dev(rs.torch_aa_table(n_in, n_out, mode))
+        tmp = torch.empty(3, n_in, n_out, device=cuda)
+        out = torch.empty(3, n_out, n_out, device=cuda)
+        pkg.ops.resample_axis(x.to(cuda), 3, n_in, n_in, 1, tab, tmp)
+        pkg.ops.resample_axis(tmp, 3, n_in, n_out, 0, tab, out)
+        assert float((out.cpu() - ref).abs().max()) < 3e-6
+    # mask branch: u8 quantisation in front, (x - 0.5) / 0.26 behind
+    m = (torch.rand(2, 126, 126, generator=g) > 0.5).float()
+    tab = dev(rs.torch_aa_table(126, 56, "bilinear"))
+    tmp, out = torch.empty(2, 126, 56, device=cuda), torch.empty(2, 56, 56, device=cuda)
+    pkg.ops.resample_axis(m.to(cuda), 2, 126, 126, 1, tab, tmp, quant_u8=True)
+    pkg.ops.resample_axis(tmp, 2, 126, 56, 0, tab, out, shift=0.5, scale=0.26)
+    want = torch.stack([opipe.alphaclip_mask_transform(mm, 56)[0] for mm in m])
+    assert float((out.cpu() - want).abs().max()) < 1e-5
+    # Pillow 8-bit path: bit exact
+    img = torch.rand(3, 126, 126, generator=g)
+    u8 = torch.empty(3, 126, 126, dtype=torch.uint8, device=cuda)
+    pkg.ops.f32_to_u8(img.to(cuda), u8)
+    assert torch.equal(u8.cpu(), (img * 255).to(torch.uint8))
+    tab = dev(rs.pil_table_u8(126, 56))
+    t8, o8 = torch.empty(3, 126, 56, dtype=torch.uint8, device=cuda), torch.empty(3, 56, 56, dtype=torch.uint8, device=cuda)
+    pkg.ops.resample_axis_u8(u8, 3, 126, 126, 1, tab, t8)
+    pkg.ops.resample_axis_u8(t8, 3, 126, 56, 0, tab, o8)
+    pil = Image.fromarray((img.permute(1, 2, 0).numpy() * 255).astype(np.uint8), "RGB").resize((56, 56), Image.BICUBIC)
+    assert torch.equal(o8.cpu(), torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1))
+
+
+# ------------------------------------------------------------------ pooling / ranking / merge / IoU
+@pytest.mark.parametrize("N,S,G", [(6, 126, 9), (3, 518, 37), (4, 100, 7)])
+def test_pool_and_stats(pkg, cuda, N, S, G):
+    g = torch.Generator().manual_seed(S)
+    masks = (torch.rand(N, S, S, generator=g) > 0.9995).float()
+    masks[0] = 0
+    masks[0, 3:40, 5:60] = 1
+    bits = torch.zeros(N, G * G, dtype=torch.uint8, device=cuda)
+    pkg.ops.pool_masks(masks.to(cuda), G, bits)
+    want = (F.adaptive_max_pool2d(masks[:, None], (G, G))[:, 0] > 0).reshape(N, -1)
+    assert torch.equal(bits.cpu().bool(), want)
+    vva, vta = torch.rand(G * G, generator=g), torch.rand(G * G, generator=g)
+    cnt = torch.zeros(N, dtype=torch.int32, device=cuda); ucnt = torch.zeros(1, dtype=torch.int32, device=cuda)
+    svv, svt = torch.zeros(N, device=cuda), torch.zeros(N, device=cuda)
+    pkg.ops.proposal_stats(bits, N, G * G, vva.to(cuda), vta.to(cuda), cnt, svv, svt, ucnt)
+    assert torch.equal(cnt.cpu().long(), want.sum(1))
+    assert int(ucnt) == int(want.any(0).sum())
+    assert float((svv.cpu() - (want * vva).sum(1)).abs().max()) < 1e-4
+    assert float((svt.cpu() - (want * vta).sum(1)).abs().max()) < 1e-4
+
+
+def test_rank_merge_matches_oracle_arithmetic(pkg, cuda):
+    rng = np.random.default_rng(0)
+    for trial, N in enumerate((6, 64, 256)):
+        emd = 0.9 + 0.1 * rng.random(N)
+        aclip = rng.normal(0.1, 0.05, N).astype(np.float32)
+        cnt = rng.integers(1, 80, N).astype(np.int32)
+        ucnt = np.array([int(cnt.max()) + 5], np.int32)
+        svv = (rng.random(N) * cnt).astype(np.float32)
+        svt = (rng.random(N) * cnt).astype(np.float32)
+        if trial == 1:
+            svv[5], svt[5], cnt[5], emd[5], aclip[5] = svv[4], svt[4], cnt[4], emd[4], aclip[4]   # an exact tie
+        t = lambda a, d=None: torch.from_numpy(a).to(cuda)
+        score = torch.zeros(N, dtype=torch.float64, device=cuda)
+        order = torch.zeros(N, dtype=torch.int32, device=cuda)
+        keep = torch.zeros(N, dtype=torch.uint8, device=cuda)
+        pkg.ops.rank(t(emd), t(aclip), t(cnt), t(svv), t(svt), t(ucnt), N, 0.85, 0.55, 0.95, score, order, keep)
+        cov = cnt / (1e-7 + ucnt[0])
+        pvv = 0.85 * (svv.astype(np.float64) / (1e-7 + cnt)) + 0.15 * cov
+        pvt = 0.85 * (svt.astype(np.float64) / (1e-7 + cnt)) + 0.15 * cov
+        es = (emd - emd.min()) / (1e-7 + emd.max() - emd.min())
+        a64 = aclip.astype(np.float64)
+        as_ = (a64 - a64.min()) / (1e-7 + a64.max() - a64.min())
+        want = (es + as_ + pvv + pvt) / 4
+        assert np.abs(score.cpu().numpy() - want).max() < 1e-12
+        want_order = sorted(range(N), key=lambda i: score.cpu().numpy()[i], reverse=True)
+        assert order.cpu().tolist() == want_order
+        top = score.cpu().numpy()[want_order[0]]
+        lb = 0.95 * top if top < 0.55 else 0.55
+        assert keep.cpu().numpy().astype(bool).tolist() == (score.cpu().numpy() >= lb).tolist()
+        masks = (torch.rand(N, 50, 50, generator=torch.Generator().manual_seed(N)) > 0.98).float()
+        merged = torch.empty(50, 50, device=cuda)
+        pkg.ops.merge_masks(masks.to(cuda), keep, merged)
+        wantm = (masks[keep.cpu().bool()].sum(0) > 0).float()
+        assert torch.equal(merged.cpu(), wantm)
+
+
+def test_cosine_scores(pkg, cuda):
+    f, t = _rand((7, 768), 1, cuda), _rand((1, 768), 2, cuda)
+    s = torch.empty(7, device=cuda)
+    pkg.ops.cosine_scores(f, t, s)
+    want = (F.normalize(f, dim=1) @ F.normalize(t, dim=1).t())[:, 0]
+    assert float((s - want).abs().max()) < 1e-6
+
+
+def test_iou_counts_match_evaluator(pkg, cuda):
+    import importlib
+    g = torch.Generator().manual_seed(1)
+    pred = (torch.rand(1, 126, 126, generator=g) > 0.5).float()
+    gt = (torch.rand(1, 126, 126, generator=g) > 0.6).float()
+    ign = ((torch.rand(1, 126, 126, generator=g) > 0.9) & (gt == 0)).float()
+    ev = importlib.import_module(pkg.__name__ + ".mars.utils.evaluation").Evaluator
+    ev.initialize()
+    for ignore in (None, ign):
+        batch = {"query_mask": gt.to(cuda)}
+        if ignore is not None:
+            batch["query_ignore_idx"] = ignore.to(cuda)
+        ai, au = ev.classify_prediction(pred.to(cuda), batch)
+        wi, wu = opipe.classify_prediction(pred[0], gt[0], None if ignore is None else ignore[0])
+        assert torch.equal(ai[:, 0].cpu(), wi) and torch.equal(au[:, 0].cpu(), wu)
+
+
+# ------------------------------------------------------------------ GradCAM backward pieces
+def test_backward_pieces_against_autograd(pkg, cuda):
+    T, D = 19, 192
+    x = _rand((T, D), 1, cuda).requires_grad_(True)
+    w, b = _rand((D,), 2, cuda), _rand((D,), 3, cuda)
+    dy = _rand((T, D), 4, cuda)
+    (gx,) = torch.autograd.grad((F.layer_norm(x, (D,), w, b, 1e-5) * dy).sum(), x)
+    dx = torch.empty(T, D, device=cuda)
+    add = _rand((T, D), 5, cuda)
+    pkg.ops.layernorm_bwd(x.detach(), w, dy, D, 1.0, 0, add, dx, 1e-5)
+    assert float((dx - (gx + add)).abs().max()) < 2e-5
+    vec = _rand((D,), 6, cuda)
+    dyb = (vec / (T - 1)).expand(T, D).clone()
+    dyb[0] = 0
+    (gx2,) = torch.autograd.grad((F.layer_norm(x, (D,), w, b, 1e-5) * dyb).sum(), x)
+    pkg.ops.layernorm_bwd(x.detach(), w, vec, 0, 1.0 / (T - 1), 1, None, dx, 1e-5)
+    assert float((dx - gx2).abs().max()) < 2e-5
+    z = _rand((T, 4 * D), 7, cuda).requires_grad_(True)
+    dh = _rand((T, 4 * D), 8, cuda)
+    (gz,) = torch.autograd.grad(((z * torch.sigmoid(1.702 * z)) * dh).sum(), z)
+    out = torch.empty_like(dh)
+    pkg.ops.quickgelu_bwd(dh, z.detach(), out)
+    assert float((out - gz).abs().max()) < 1e-5
+    s = _rand((3, T, 64), 9, cuda).requires_grad_(True)
+    dP = _rand((3, T, 64), 10, cuda)
+    p = torch.zeros(3, T, 64, device=cuda)
+    pr = s[..., :T].softmax(-1)
+    (gs,) = torch.autograd.grad((pr * dP[..., :T]).sum(), s)
+    p[..., :T] = pr.detach()
+    dS = torch.empty(3, T, 64, device=cuda)
+    pkg.ops.softmax_bwd(p, dP, dS, 64, 3, T, 0.125)
+    assert float((dS[..., :T] - gs[..., :T] * 0.125).abs().max()) < 1e-6 and float(dS[..., T:].abs().max()) == 0
+    m = torch.empty(D, device=cuda)
+    pkg.ops.col_mean(dy, 1, T, m)
+    assert float((m - dy[1:].mean(0)).abs().max()) < 1e-6
+    cam = torch.empty(T - 1, device=cuda)
+    pkg.ops.cam_rows(dy, m, 1, T - 1, cam)
+    assert float((cam - torch.relu(dy[1:] @ m)).abs().max()) < 1e-5
+    # head: logits and d logits[0] / d f
+    E = 64
+    f = _rand((D,), 11, cuda).requires_grad_(True)
+    proj, text = _rand((D, E), 12, cuda, 0.1), _rand((2, E), 13, cuda)
+    gg = f @ proj
+    logits = (14.285714 * (gg / gg.norm()) @ (text / text.norm(dim=1, keepdim=True)).t()).softmax(-1)
+    (gf,) = torch.autograd.grad(logits[0], f)
+    lo, df = torch.empty(2, device=cuda), torch.empty(D, device=cuda)
+    pkg.ops.cam_head(f.detach(), proj, text, 14.285714, lo, df)
+    assert float((lo - logits.detach()).abs().max()) < 1e-5
+    assert float((df - gf).abs().max()) < 1e-5 * max(1.0, float(gf.abs().max()))

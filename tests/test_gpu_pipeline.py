@@ -1,0 +1,123 @@
+"""Whole ranking path on the GPU against the CPU oracle on the same seeded episode, and the
+size-independent properties that must hold at any configuration."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import maxdiff, run_tiny_episode_parity, tiny_config
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _build(pkg, cfg):
+    MARS = importlib.import_module(pkg.__name__ + ".mars.MARS")
+    return MARS.build_MARS_fss(cfg["args"], state_dicts=cfg["sds"])
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_tiny_episode_fp32_parity(pkg, cuda, seed):
+    rep = run_tiny_episode_parity(pkg, device="cuda:0", seed=seed, dtype=torch.float32, tol=TOL)
+    assert rep["order_equal"], rep
+    assert rep["mask_mismatch"] == 0, rep
+
+
+def test_components_against_oracle(pkg, cuda):
+    cfg = tiny_config(pkg)
+    ep = pkg.synth.make_episode(7, size=cfg["size"], nshot=cfg["nshot"], nprop=cfg["nprop"])
+    mars = _build(pkg, cfg)
+    dev = cuda
+    vva_mod = mars.visual_visual_alignment_component
+    vva = vva_mod.compute(ep["support_imgs"].to(dev), ep["support_masks"].to(dev), ep["query_img"].to(dev))
+    ref = opipe.vva_compute(cfg["oracle_models"]["dino_sd"], cfg["oracle_models"]["dino_kw"], ep["support_imgs"],
+                            ep["support_masks"], ep["query_img"])
+    assert maxdiff(vva_mod.similarity_matrix, ref["similarity"]) < TOL
+    assert maxdiff(vva_mod.cost_matrix, ref["cost"]) < TOL
+    assert maxdiff(vva_mod.vva_raw, ref["vva_raw"]) < TOL
+    P = ref["mean_attn"].shape[0]
+    assert maxdiff(vva_mod.mean_attn[:, :P], ref["mean_attn"]) < TOL
+    assert maxdiff(vva, ref["vva"]) < TOL
+    vta_mod = mars.visual_text_alignment_component
+    vta = vta_mod.compute(ep["query_img"].to(dev), "object", [])
+    rt = opipe.vta_compute(cfg["oracle_models"]["clip_sd"], cfg["oracle_models"]["clip_kw"], ep["query_img"],
+                           cfg["tokens"]["fg"], cfg["tokens"]["bg"])
+    assert maxdiff(vta_mod.logits, rt["logits"]) < TOL
+    assert maxdiff(vta_mod.cam, rt["cam"]) < 5e-4
+    Pv = rt["mean_attn"].shape[0]
+    assert maxdiff(vta_mod.mean_attn[:, :Pv], rt["mean_attn"]) < TOL
+    assert maxdiff(vta, rt["vta"]) < 5e-4 * max(1.0, float(rt["vta"].abs().max()))
+
+
+def test_five_shot_episode(pkg, cuda):
+    cfg = tiny_config(pkg, nshot=5, nprop=8)
+    ep = pkg.synth.make_episode(21, size=cfg["size"], nshot=5, nprop=8)
+    mars = _build(pkg, cfg)
+    pred = mars.predict(ep["support_imgs"].to(cuda), ep["support_masks"].to(cuda), ep["query_img"].to(cuda),
+                        ep["mask_proposals"].to(cuda))
+    ref = opipe.mars_predict(cfg["oracle_models"], ep, cfg["tokens"])
+    got = mars.filtering_merging_component.scores()
+    assert maxdiff(got["emd"], ref["scores"]["emd"]) < TOL
+    assert maxdiff(got["score"], ref["scores"]["score"]) < TOL
+    assert got["order"].tolist() == ref["scores"]["order"].tolist()
+    assert int((pred.cpu() != ref["mask"]).sum()) == 0
+
+
+def test_bf16_run_ranks_like_fp32(pkg, cuda):
+    """bf16 cannot meet 1e-4; it is judged on rank agreement and mask overlap with the fp32 run."""
+    rep32 = run_tiny_episode_parity(pkg, device="cuda:0", seed=3, dtype=torch.float32)
+    rep16 = run_tiny_episode_parity(pkg, device="cuda:0", seed=3, dtype=torch.bfloat16)
+    print("bf16 vs oracle:", rep16, "fp32 vs oracle:", rep32)
+    assert all(np.isfinite(v) for k, v in rep16.items() if isinstance(v, float)), rep16
+    assert rep16["emd"] < 0.05 and rep16["score"] < 0.25, rep16
+
+
+def test_properties_merge_and_iou(pkg, cuda):
+    """Idempotence and order independence: merging the merged mask with itself changes nothing, the
+    kept set does not depend on proposal order, IoU counts add up to the pixel count."""
+    cfg = tiny_config(pkg)
+    ep = pkg.synth.make_episode(9, size=cfg["size"], nshot=1, nprop=6)
+    mars = _build(pkg, cfg)
+    args = [ep["support_imgs"].to(cuda), ep["support_masks"].to(cuda), ep["query_img"].to(cuda)]
+    pred = mars.predict(*args, ep["mask_proposals"].to(cuda)).clone()
+    perm = torch.tensor([3, 0, 5, 1, 4, 2])
+    pred_p = mars.predict(*args, ep["mask_proposals"][perm].to(cuda)).clone()
+    assert torch.equal(pred, pred_p)
+    keep = torch.ones(2, dtype=torch.uint8, device=cuda)
+    again = torch.empty_like(pred)
+    pkg.ops.merge_masks(torch.stack([pred, pred]).contiguous(), keep, again)
+    assert torch.equal(again, pred)
+    ev = importlib.import_module(pkg.__name__ + ".mars.utils.evaluation").Evaluator
+    ev.initialize()
+    ai, au = ev.classify_prediction(pred[None], {"query_mask": ep["query_mask"].to(cuda)})
+    n = pred.numel()
+    assert float(au.sum() + ai.sum()) == float(2 * n)       # |pred_k| + |gt_k| summed over both bins
+    meter = importlib.import_module(pkg.__name__ + ".mars.utils.logger").AverageMeter
+    ds = type("DS", (), {"benchmark": "coco", "class_ids": [0, 4, 8]})()
+    am = meter(ds, device=cuda)
+    am.update(ai, au, ep["class_id"].to(cuda))
+    miou, fb, _ = am.compute_iou()
+    wi, wu = opipe.classify_prediction(pred.cpu(), ep["query_mask"][0])
+    inter = torch.zeros(2, 80); union = torch.zeros(2, 80)
+    inter[:, int(ep["class_id"])] = wi; union[:, int(ep["class_id"])] = wu
+    m_ref, fb_ref = opipe.compute_iou(inter, union, [0, 4, 8])
+    assert abs(float(miou) - m_ref) < 1e-4 and abs(float(fb) - fb_ref) < 1e-4
+
+
+def test_reference_signature_with_explicit_cost_matrix(pkg, cuda):
+    """FilteringMergingModule.compute called the reference way: cost_matrix as a CPU tensor."""
+    cfg = tiny_config(pkg)
+    ep = pkg.synth.make_episode(3, size=cfg["size"], nshot=1, nprop=6)
+    mars = _build(pkg, cfg)
+    pred = mars.predict(ep["support_imgs"].to(cuda), ep["support_masks"].to(cuda), ep["query_img"].to(cuda),
+                        ep["mask_proposals"].to(cuda)).clone()
+    s1 = mars.filtering_merging_component.scores()["score"].clone()
+    vva_mod = mars.visual_visual_alignment_component
+    out = mars.filtering_merging_component.compute(
+        query_img=ep["query_img"].to(cuda), mask_proposals=ep["mask_proposals"].to(cuda), support_mask=ep["support_masks"].to(cuda),
+        cost_matrix=vva_mod.cost_matrix, patch_features_spatial_dimension=vva_mod.model_embedding_spatial_dimensions,
+        vva=mars.vva, vta=mars.vta, text=["a object."])
+    assert torch.equal(out, pred)
+    assert maxdiff(mars.filtering_merging_component.scores()["score"], s1) < 1e-12

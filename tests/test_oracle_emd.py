@@ -1,0 +1,66 @@
+"""Exact EMD: the oracle's C solver against scipy HiGHS, and the shipped host solver (network
+simplex in libmars_hip.so) against the oracle.  POT itself is absent (parity unpinned against the
+wheel); the LP optimum is unique, so two independent exact solvers pin the value."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle.emd import emd2_highs, emd2_uniform
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 9), (6, 1), (4, 4), (17, 5), (30, 45), (64, 64)])
+def test_oracle_ssp_matches_highs(n, m):
+    rng = np.random.default_rng(n * 100 + m)
+    M = rng.random((n, m))
+    assert abs(emd2_uniform(M) - emd2_highs(M)) < 1e-10
+
+
+def test_oracle_known_answers():
+    assert emd2_uniform(np.zeros((3, 4))) == 0.0
+    assert abs(emd2_uniform(np.full((5, 2), 0.25)) - 0.25) < 1e-15
+    # identity assignment: zero diagonal, unit off-diagonal
+    assert abs(emd2_uniform(1.0 - np.eye(6))) < 1e-15
+    # 2 sources, 1 sink: mean of the column
+    assert abs(emd2_uniform(np.array([[0.2], [0.6]])) - 0.4) < 1e-15
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 9), (6, 1), (2, 2), (16, 16), (17, 5), (30, 45), (64, 64), (200, 120), (333, 333)])
+def test_product_simplex_matches_oracle(pkg, n, m):
+    lib = pkg.hip.lib()
+    rng = np.random.default_rng(7 * n + m)
+    M = np.ascontiguousarray(rng.random((n, m)))
+    got = lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), n, m)
+    assert abs(got - emd2_uniform(M)) < 1e-10
+
+
+def test_product_simplex_degenerate_costs(pkg):
+    """Ties everywhere (quantised costs, equal marginals): the perturbed simplex must still stop at
+    the optimum."""
+    lib = pkg.hip.lib()
+    rng = np.random.default_rng(5)
+    for n, m in ((40, 40), (60, 30), (25, 100)):
+        M = np.ascontiguousarray(np.round(rng.random((n, m)), 1))
+        got = lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), n, m)
+        assert abs(got - emd2_uniform(M)) < 1e-10
+    M = np.zeros((50, 50))
+    assert lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), 50, 50) == 0.0
+
+
+def test_product_emd_scores_batch(pkg):
+    """marshost_emd_scores: gather of C = (1-S)/2 (float32) by support rows and mask columns, threads."""
+    import torch
+    ops = pkg.ops
+    rng = np.random.default_rng(1)
+    R, P, N = 50, 40, 7
+    S = torch.from_numpy(rng.uniform(-1, 1, (R, 64)).astype(np.float32))
+    fg = torch.from_numpy((rng.random(R) < 0.4).astype(np.uint8))
+    bits = torch.from_numpy((rng.random((N, P)) < 0.3).astype(np.uint8))
+    bits[:, 0] = 1
+    got = ops.emd_scores_host(S, fg, bits, threads=3)
+    C = ((1 - S[:, :P]) / 2).numpy()
+    for k in range(N):
+        M = C[fg.numpy().astype(bool)][:, bits[k].numpy().astype(bool)].astype(np.float64)
+        assert abs(float(got[k]) - (1 - emd2_uniform(M))) < 1e-10
+    got2 = ops.emd_scores_host(torch.from_numpy(C).contiguous(), fg, bits, threads=1, is_cost=True)
+    assert float((got - got2).abs().max()) < 1e-12
