@@ -493,7 +493,7 @@ class AlphaCLIP(_TextTower):
         self.conv_alpha = Lin(sd["visual.conv1_alpha.weight"].reshape(W, p * p), None, dtype, device)
         self.conv_rgba = Lin(w_rgba, None, dtype, device)
         self.class_embedding = sd["visual.class_embedding"].float().to(device)
-        self.pos = sd["visual.positional_embedding"].float().to(device).contiguous()
+        self.vpos = sd["visual.positional_embedding"].float().to(device).contiguous()
         self.ln_pre = Norm(sd, "visual.ln_pre", device, 1e-5)
         self.ln_post = Norm(sd, "visual.ln_post", device, 1e-5)
         self.vproj_t = Lin(sd["visual.proj"].t().contiguous(), None, torch.float32, device)  # [E, W]
@@ -531,16 +531,16 @@ class AlphaCLIP(_TextTower):
         if shared:
             # rgb[Pn, D] = conv1(image) + pos[1:], then X[b, 1+i] = conv1_alpha(alpha_b)[i] + rgb[i]
             ops.gemm(cols_rgb, self.conv_rgb.w, b["rgb"], Pn, D, self.conv_rgb.Kp, lda=self.conv_rgb.Kp, ldb=self.conv_rgb.Kp,
-                     ldc=D, residual=self.pos, r_off=D, ldr=D)
+                     ldc=D, residual=self.vpos, r_off=D, ldr=D)
             ops.gemm(b["cols_a"], self.conv_alpha.w, X, Pn, D, self.conv_alpha.Kp, lda=self.conv_alpha.Kp, ldb=self.conv_alpha.Kp,
                      ldc=D, c_off=D, nb0=n, sA=(Pn * self.conv_alpha.Kp, 0), sC=(T * D, 0), residual=b["rgb"], ldr=D)
         else:
             ops.gemm(cols_rgb, self.conv_rgb.w, X, Pn, D, self.conv_rgb.Kp, lda=self.conv_rgb.Kp, ldb=self.conv_rgb.Kp, ldc=D,
-                     c_off=D, nb0=n, sA=(Pn * self.conv_rgb.Kp, 0), sC=(T * D, 0), residual=self.pos, r_off=D, ldr=D)
+                     c_off=D, nb0=n, sA=(Pn * self.conv_rgb.Kp, 0), sC=(T * D, 0), residual=self.vpos, r_off=D, ldr=D)
             ops.gemm(b["cols_a"], self.conv_alpha.w, X, Pn, D, self.conv_alpha.Kp, lda=self.conv_alpha.Kp, ldb=self.conv_alpha.Kp,
                      ldc=D, c_off=D, nb0=n, sA=(Pn * self.conv_alpha.Kp, 0), sC=(T * D, 0), residual=X, r_off=D, ldr=D,
                      sR=(T * D, 0))
-        ops.write_prefix_tokens(X, self.class_embedding, self.pos[0], None)
+        ops.write_prefix_tokens(X, self.class_embedding, self.vpos[0], None)
         X2 = X.view(n * T, D)
         ops.layernorm(X2, self.ln_pre.w, self.ln_pre.b, X2, self.ln_pre.eps)
         for blk in self.vtower.blocks:

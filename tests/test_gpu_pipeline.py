@@ -95,14 +95,15 @@ def test_properties_merge_and_iou(pkg, cuda):
     n = pred.numel()
     assert float(au.sum() + ai.sum()) == float(2 * n)       # |pred_k| + |gt_k| summed over both bins
     meter = importlib.import_module(pkg.__name__ + ".mars.utils.logger").AverageMeter
-    ds = type("DS", (), {"benchmark": "coco", "class_ids": [0, 4, 8]})()
+    ids = sorted({0, 4, int(ep["class_id"])})
+    ds = type("DS", (), {"benchmark": "coco", "class_ids": ids})()
     am = meter(ds, device=cuda)
     am.update(ai, au, ep["class_id"].to(cuda))
     miou, fb, _ = am.compute_iou()
     wi, wu = opipe.classify_prediction(pred.cpu(), ep["query_mask"][0])
     inter = torch.zeros(2, 80); union = torch.zeros(2, 80)
     inter[:, int(ep["class_id"])] = wi; union[:, int(ep["class_id"])] = wu
-    m_ref, fb_ref = opipe.compute_iou(inter, union, [0, 4, 8])
+    m_ref, fb_ref = opipe.compute_iou(inter, union, ids)
     assert abs(float(miou) - m_ref) < 1e-4 and abs(float(fb) - fb_ref) < 1e-4
 
 
