@@ -47,6 +47,10 @@ typedef struct MarsGemm {
  * alpha_clip/model.py:222,251,359-361; VisualVisualAlignmentModule.py:69,78-79;
  * PriorInformationRefinementModule.py:74-79. out = residual + gamma*act(alpha*A.B^T + bias). */
 int marship_gemm(const MarsGemm* g, void* stream);
+/* Tuning hook (no reference counterpart): selects the GEMM kernel variant, returns the previous
+ * one. 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
+ * 3 = LDS-DMA ring 256x256, 4 = chosen by shape (default). */
+int marship_set_gemm_variant(int variant);
 
 /* ---- ViT glue ------------------------------------------------------------------ */
 /* nn.LayerNorm over the last dim (dinov2 vision_transformer.py:97 eps 1e-6; clip/model.py:265-271

@@ -43,28 +43,57 @@ __device__ __forceinline__ bf16x8 load_vt_frag(const unsigned char* vt, int lane
     return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256) void flash_attn_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ O,
-                                                         float* __restrict__ lse, int T, int H, int causal) {
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU:
+// v_permlane16_swap exchanges odd rows of its first operand with even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second, so feeding
+// the same value twice leaves {row, partner row} side by side in the two results.
+__device__ __forceinline__ float rows_max(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    u = __builtin_bit_cast(unsigned, x);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    u = __builtin_bit_cast(unsigned, x);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// QB query blocks of 16 per wave, NW waves per workgroup: one K/V tile in LDS serves NW*QB*16
+// queries, and a wave re-uses its K and V^T fragments (held in registers) for all its QB blocks,
+// which is what takes the LDS read traffic off the critical path.
+template <int QB, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ O,
+                                                             float* __restrict__ lse, int T, int H, int causal) {
+    constexpr int THREADS = NW * 64, QPB = NW * QB * 16, CPT = 512 / THREADS;  // chunks per thread, tile and operand
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KT * ROWB];  // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
     const int D = H * 64;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * QPB + wave * (QB * 16);
     const int64_t row_b = (int64_t)3 * D * 2;  // bytes per token row of qkv
     const unsigned char* base = (const unsigned char*)qkv + (int64_t)b * T * row_b + (int64_t)h * 128;
 
-    // Q^T operand: lane = query r16, d = 8g + j (+32 for the second k-step)
-    const int qrow = min(q0 + r16, T - 1);
-    const unsigned char* qp = base + (int64_t)qrow * row_b;
-    const bf16x8 qf0 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 16 * g));
-    const bf16x8 qf1 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 + 16 * g));
-
-    // staging: 512 chunks per tile and operand, 2 per thread
-    const unsigned char* kp[2]; const unsigned char* vp[2]; int dst[2]; int srow[2];
+    // Q^T operands: lane = query r16 of block qb, d = 8g + j (+32 for the second k-step)
+    bf16x8 qf[QB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int qd = tid + 256 * i;
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 16 + r16, T - 1);
+        const unsigned char* qp = base + (int64_t)qrow * row_b;
+        qf[qb][0] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 16 * g));
+        qf[qb][1] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 + 16 * g));
+    }
+
+    const unsigned char* kp[CPT]; const unsigned char* vp[CPT]; int dst[CPT]; int srow[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int qd = tid + THREADS * i;
         srow[i] = qd >> 3;
         const int c = qd & 7;
         kp[i] = base + (int64_t)D * 2 + c * 16;
@@ -72,10 +101,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const __bf16* __restric
         dst[i] = tile_off(srow[i], c);
     }
     const int nt = (T + KT - 1) / KT;
-    uint4 rk[2], rv[2];
+    uint4 rk[CPT], rv[CPT];
     auto gload = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CPT; ++i) {
             const int key = min(t * KT + srow[i], T - 1);
             rk[i] = *(const uint4*)(kp[i] + (int64_t)key * row_b);
             rv[i] = *(const uint4*)(vp[i] + (int64_t)key * row_b);
@@ -83,18 +112,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const __bf16* __restric
     };
     auto swrite = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { *(uint4*)(&lds[buf][0][dst[i]]) = rk[i]; *(uint4*)(&lds[buf][1][dst[i]]) = rv[i]; }
+        for (int i = 0; i < CPT; ++i) { *(uint4*)(&lds[buf][0][dst[i]]) = rk[i]; *(uint4*)(&lds[buf][1][dst[i]]) = rv[i]; }
     };
 
-    f32x4 o[4];
+    f32x4 o[QB][4];
+    float mrun[QB], lrun[QB];   // running max of s*c and sum of 2^(s*c - max), c = log2(e)/8
 #pragma unroll
-    for (int m = 0; m < 4; ++m) o[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun = -INFINITY, lrun = 0.f;
-    const float scale = 0.125f;
-    const int myq = q0 + r16;
+    for (int qb = 0; qb < QB; ++qb) {
+        mrun[qb] = -INFINITY; lrun[qb] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o[qb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float c2 = 0.125f * 1.44269504088896340736f;
 
-    // causal: tiles past the last query of this block are never needed
-    const int nt_eff = causal ? min(nt, (blockIdx.x * 64 + 63) / KT + 1) : nt;
+    // causal: tiles past the last query of this workgroup are never needed
+    const int nt_eff = causal ? min(nt, (blockIdx.x * QPB + QPB - 1) / KT + 1) : nt;
     gload(0); swrite(0);
     __syncthreads();
     for (int t = 0; t < nt_eff; ++t) {
@@ -102,68 +134,86 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const __bf16* __restric
         if (t + 1 < nt_eff) gload(t + 1);
         const unsigned char* kt_ = &lds[buf][0][0];
         const unsigned char* vt_ = &lds[buf][1][0];
-        f32x4 s[4];
+        bf16x8 kf[4][2], vf[4][2];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, g)));
-            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, 4 + g)));
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, acc, 0, 0, 0);
-            s[f] = acc;
+            kf[f][0] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, g)));
+            kf[f][1] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, 4 + g)));
         }
-        // mask + running max (lane holds keys t*64 + 16f + 4g + j for query r16)
-        float mx = -INFINITY;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int m = 0; m < 4; ++m) { vf[m][0] = load_vt_frag(vt_, lane, m, 0); vf[m][1] = load_vt_frag(vt_, lane, m, 1); }
+        const bool need_mask = (t * KT + KT > T) || causal;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = t * KT + 16 * f + 4 * g + j;
-                float v = s[f][j] * scale;
-                if (key >= T || (causal && key > myq)) v = -INFINITY;
-                s[f][j] = v;
-                mx = fmaxf(mx, v);
+        for (int qb = 0; qb < QB; ++qb) {
+            f32x4 s[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][0], qf[qb][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][1], qf[qb][1], acc, 0, 0, 0);
+                s[f] = acc;
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = (mnew == -INFINITY) ? 1.f : expf(mrun - mnew);
-        float ps = 0.f;
+            // lane holds keys t*64 + 16f + 4g + j of query q0 + 16qb + r16
+            if (need_mask) {
+                const int myq = q0 + qb * 16 + r16;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float p = (mnew == -INFINITY) ? 0.f : expf(s[f][j] - mnew);
-                s[f][j] = p;
-                ps += p;
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = t * KT + 16 * f + 4 * g + j;
+                        if (key >= T || (causal && key > myq)) s[f][j] = -INFINITY;
+                    }
             }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        lrun = lrun * alpha + ps;
-        mrun = mnew;
+            float mx = -INFINITY;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { o[m][0] *= alpha; o[m][1] *= alpha; o[m][2] *= alpha; o[m][3] *= alpha; }
-        const bf16x8 p0 = pack_bf16x8(s[0], s[1]);
-        const bf16x8 p1 = pack_bf16x8(s[2], s[3]);
+            for (int f = 0; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
+            mx = rows_max(mx);
+            const float mnew = fmaxf(mrun[qb], mx * c2);
+            const bool dead = mnew == -INFINITY;                       // every key so far is masked
+            const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+            float ps = 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            o[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag(vt_, lane, m, 0), p0, o[m], 0, 0, 0);
-            o[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag(vt_, lane, m, 1), p1, o[m], 0, 0, 0);
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[f][j], c2, -mnew));
+                    s[f][j] = p;
+                    ps += p;
+                }
+            ps = rows_sum(ps);
+            lrun[qb] = lrun[qb] * alpha + ps;
+            mrun[qb] = mnew;
+            if (!__all(alpha == 1.f)) {   // the running max moved for some query of this block
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { o[qb][m][0] *= alpha; o[qb][m][1] *= alpha; o[qb][m][2] *= alpha; o[qb][m][3] *= alpha; }
+            }
+            const bf16x8 p0 = pack_bf16x8(s[0], s[1]);
+            const bf16x8 p1 = pack_bf16x8(s[2], s[3]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][0], p0, o[qb][m], 0, 0, 0);
+                o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][1], p1, o[qb][m], 0, 0, 0);
+            }
         }
         if (t + 1 < nt_eff) swrite(buf ^ 1);
         __syncthreads();
     }
-    if (myq < T) {
-        const float inv = 1.0f / lrun;
-        __bf16* op = O + ((int64_t)b * T + myq) * D + h * 64;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            bf16x4 v;
-            v[0] = (__bf16)(o[m][0] * inv); v[1] = (__bf16)(o[m][1] * inv);
-            v[2] = (__bf16)(o[m][2] * inv); v[3] = (__bf16)(o[m][3] * inv);
-            *(bf16x4*)(op + 16 * m + 4 * g) = v;
+    for (int qb = 0; qb < QB; ++qb) {
+        const int myq = q0 + qb * 16 + r16;
+        if (myq < T) {
+            const float inv = 1.0f / lrun[qb];
+            __bf16* op = O + ((int64_t)b * T + myq) * D + h * 64;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                bf16x4 v;
+                v[0] = (__bf16)(o[qb][m][0] * inv); v[1] = (__bf16)(o[qb][m][1] * inv);
+                v[2] = (__bf16)(o[qb][m][2] * inv); v[3] = (__bf16)(o[qb][m][3] * inv);
+                *(bf16x4*)(op + 16 * m + 4 * g) = v;
+            }
+            // natural-log LSE of the scaled scores: (max + log2(sum)) * ln 2
+            if (lse && g == 0) lse[(int64_t)bh * T + myq] = (mrun[qb] + log2f(lrun[qb])) * 0.69314718055994530942f;
         }
-        if (lse && g == 0) lse[(int64_t)bh * T + myq] = mrun + logf(lrun);
     }
 }
 
@@ -225,8 +275,13 @@ extern "C" int marship_flash_attn(const void* qkv, void* O, float* lse, int B, i
     MARS_CHECK(qkv && O, "flash_attn: null pointer");
     MARS_CHECK(B > 0 && T > 0 && H > 0 && (int64_t)B * H <= 65535, "flash_attn: bad shape B=%d T=%d H=%d", B, T, H);
     MARS_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)O % 8) == 0, "flash_attn: misaligned buffers");
-    dim3 grid((T + 63) / 64, B * H), block(256);
-    hipLaunchKernelGGL(flash_attn_kernel, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, causal);
+    if (T <= 96) {   // short (text) sequences: 32 queries per wave, 2 waves
+        dim3 grid((T + 63) / 64, B * H), block(128);
+        hipLaunchKernelGGL((flash_attn_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, causal);
+    } else {         // 32 queries per wave, 4 waves: 128 queries per workgroup
+        dim3 grid((T + 127) / 128, B * H), block(256);
+        hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, causal);
+    }
     MARS_LAUNCH_CHECK();
     return 0;
 }

@@ -157,6 +157,18 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(MarsGemm g) {
 
 }  // namespace
 
+void mars_gemm_glds_launch(const MarsGemm& g, hipStream_t s, int variant);
+void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s);
+static int g_gemm_variant = 4;
+
+// Tuning hook: 0 = register-staged 128x128, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
+// 3 = LDS-DMA ring 256x256, 4 = choose by shape (default).
+extern "C" int marship_set_gemm_variant(int v) {
+    const int old = g_gemm_variant;
+    if (v >= 0 && v <= 4) g_gemm_variant = v;
+    return old;
+}
+
 extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     MARS_CHECK(g && g->A && g->B && g->C, "gemm: null operand");
     MARS_CHECK(g->M > 0 && g->N > 0 && g->K > 0 && g->nb0 > 0 && g->nb1 > 0, "gemm: bad shape M=%d N=%d K=%d", g->M, g->N, g->K);
@@ -172,6 +184,18 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     const int ntm = (g->M + BM - 1) / BM, ntn = (g->N + BN - 1) / BN;
     dim3 grid(ntm * ntn, g->nb0 * g->nb1), block(THREADS);
     hipStream_t s = (hipStream_t)stream;
+    if (g_gemm_variant != 0) {
+        int v = g_gemm_variant;
+        if (v == 4) {
+            // the 256x256 ring needs at least one full wave of workgroups to pay off
+            const int64_t big = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256) * g->nb0 * g->nb1;
+            v = big >= 192 ? 3 : 1;
+        }
+        if (v == 3) mars_gemm_ring_launch(*g, s);
+        else mars_gemm_glds_launch(*g, s, v);
+        MARS_LAUNCH_CHECK();
+        return 0;
+    }
     if (g->in_dtype == 1) {
         if (g->out_dtype == 1) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, __bf16>), grid, block, 0, s, *g);
         else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, float>), grid, block, 0, s, *g);

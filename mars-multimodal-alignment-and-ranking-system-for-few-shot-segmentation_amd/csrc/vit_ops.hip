@@ -48,6 +48,47 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// vector form: every lane owns float4 chunks (i*64 + lane), rows and pointers 16-byte aligned
+template <typename TOUT, int NCH>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int64_t xs,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            TOUT* __restrict__ y, int64_t ys, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4* xr = (const f32x4*)(x + (int64_t)row * xs);
+    const int nc = D >> 2;                 // chunks per row
+    f32x4 v[NCH];                          // NCH = ceil(D / 256) chunks per lane
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) {
+            v[i] -= mean;
+            q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    TOUT* yr = y + (int64_t)row * ys;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) {
+            const f32x4 wv = ((const f32x4*)w)[c], bv = ((const f32x4*)b)[c];
+            const f32x4 o = v[i] * rstd * wv + bv;
+            if constexpr (sizeof(TOUT) == 4) ((f32x4*)yr)[c] = o;
+            else { bf16x4 ob; ob[0] = (__bf16)o[0]; ob[1] = (__bf16)o[1]; ob[2] = (__bf16)o[2]; ob[3] = (__bf16)o[3]; ((bf16x4*)yr)[c] = ob; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- im2col
 // one thread per output element of the real (unpadded) K range
 template <typename TOUT, typename TIN>
@@ -223,7 +264,18 @@ extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* 
     MARS_CHECK(x && w && b && y, "layernorm: null pointer");
     MARS_CHECK(rows > 0 && D > 0 && D <= 2048, "layernorm: D=%d out of range (1..2048)", D);
     dim3 grid((rows + 3) / 4), block(256);
-    if (out_dtype == 1) hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps);
+    const int ysz = out_dtype == 1 ? 2 : 4;
+    const bool vec = D % 4 == 0 && x_stride % 4 == 0 && y_stride % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
+                     (uintptr_t)b % 16 == 0 && (uintptr_t)y % (4 * ysz) == 0;
+    if (vec) {
+        const int nch = (D / 4 + 63) / 64;
+#define MARS_LN(N)                                                                                                         \
+        if (out_dtype == 1) hipLaunchKernelGGL((layernorm_vec_kernel<__bf16, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps); \
+        else hipLaunchKernelGGL((layernorm_vec_kernel<float, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
+        if (nch <= 1) { MARS_LN(1) } else if (nch == 2) { MARS_LN(2) } else if (nch == 3) { MARS_LN(3) } else if (nch == 4) { MARS_LN(4) }
+        else if (nch <= 6) { MARS_LN(6) } else { MARS_LN(8) }
+#undef MARS_LN
+    } else if (out_dtype == 1) hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps);
     else hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
     MARS_LAUNCH_CHECK();
     return 0;

@@ -4,8 +4,8 @@ Interface of /root/reference/mars/components/VisualVisualAlignmentModule.py:13-1
 ``compute(support_imgs, support_masks, query_img) -> [G, G]`` with the side outputs
 ``similarity_matrix`` / ``cost_matrix`` (CPU tensors) and ``clear()``.
 
-Differences in *how*, not *what*: two ViT passes instead of three (the attention maps
-are averaged inside the query pass and never materialised), one similarity GEMM
+Differences in *how*, not *what*: one batched ViT pass over query + supports instead of three
+passes (the attention maps are averaged inside it and never materialised), one similarity GEMM
 instead of two, the normalisation fused into the patch extraction, and the
 device-to-host copy of S is asynchronous so the exact-EMD stage can overlap the GPU.
 """
@@ -78,8 +78,7 @@ class VisualVisualAlignmentModule:
             dev = self.device
             w = self._ws[key] = dict(
                 ld=ld,
-                Fs=torch.zeros(ns * P, D, dtype=torch.float32, device=dev),
-                Fq=torch.zeros(P, D, dtype=torch.float32, device=dev),
+                F=torch.zeros((ns + 1) * P, D, dtype=torch.float32, device=dev),
                 S=torch.zeros(ns * P, ld, dtype=torch.float32, device=dev),
                 S_host=torch.zeros(ns * P, ld, dtype=torch.float32).pin_memory(),
                 bits=torch.zeros(ns * P, dtype=torch.uint8, device=dev),
@@ -98,15 +97,16 @@ class VisualVisualAlignmentModule:
         P, R, D = G * G, self.model_num_regs, m.embed_dim
         ns = support_imgs.shape[1]
         w = self._buffers(ns, P, D)
-        # lines 66-68: support features, query features and the query's attention maps (two passes)
-        Xs = m.forward_tokens(support_imgs[0], self._mean, self._std)
+        # lines 66-68: support features, query features and the query's attention maps in ONE batched
+        # pass (query first, so that the attention-mean side output reads image 0)
         acc = self.pir.new_accumulator(P)
-        Xq = m.forward_tokens(query_img, self._mean, self._std, mean_attn=(acc, self.last_n))
-        ops.l2norm_rows(Xs, 1 + R, P, w["Fs"])
-        ops.l2norm_rows(Xq, 1 + R, P, w["Fq"])
+        imgs = torch.cat([query_img, support_imgs[0]], dim=0)
+        X = m.forward_tokens(imgs, self._mean, self._std, mean_attn=(acc, self.last_n))
+        ops.l2norm_rows(X, 1 + R, P, w["F"])
+        w_fq, w_fs = w["F"][:P], w["F"][P:]
         # line 69: S = F_s F_q^T, then the asynchronous host copy the EMD stage waits on
         S = w["S"]
-        ops.linear(w["Fs"], w["Fq"], S[:, :P])
+        ops.linear(w_fs, w_fq, S[:, :P])
         w["S_host"].copy_(S, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

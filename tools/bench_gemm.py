@@ -1,0 +1,78 @@
+"""GEMM micro-benchmark: every kernel variant on the shapes of the AlphaCLIP / DINOv2 towers,
+interleaved in one process, with a correctness check against torch on random data."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+ops, lib = pkg.ops, pkg.hip.lib()
+dev = torch.device("cuda:0")
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2").split(",")]
+ROUNDS = int(os.environ.get("ROUNDS", "5"))
+
+# (name, M, N, K, out dtype, epilogue)
+SHAPES = [
+    ("aclip qkv   ", 36928, 3072, 1024, torch.bfloat16, "bias"),
+    ("aclip proj  ", 36928, 1024, 1024, torch.float32, "res"),
+    ("aclip fc1   ", 36928, 4096, 1024, torch.bfloat16, "gelu"),
+    ("aclip fc2   ", 36928, 1024, 4096, torch.float32, "res"),
+    ("dino  qkv   ", 1374, 3072, 1024, torch.bfloat16, "bias"),
+    ("dino  fc2   ", 1374, 1024, 4096, torch.float32, "res"),
+    ("clip  fc1   ", 1090, 3072, 768, torch.bfloat16, "gelu"),
+]
+
+
+def run(shape, variant, a, b, out, bias, res):
+    name, M, N, K, odt, epi = shape
+    lib.marship_set_gemm_variant(variant)
+    kw = {}
+    if epi in ("bias", "gelu", "res"):
+        kw["bias"] = bias
+    if epi == "gelu":
+        kw["act"] = 2
+    if epi == "res":
+        kw["residual"] = out
+    ops.linear(a, b, out, **kw)
+
+
+for shape in SHAPES:
+    name, M, N, K, odt, epi = shape
+    g = torch.Generator(device="cpu").manual_seed(0)
+    a = (torch.rand(M, K, generator=g) * 2 - 1).to(dev).to(torch.bfloat16)
+    b = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).to(dev).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(dev)
+    flops = 2.0 * M * N * K
+    # correctness of each variant on the first 300 rows
+    ref = a[:300].float() @ b.float().t() + bias
+    if epi == "gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    for v in VARIANTS:
+        out = torch.zeros(M, N, device=dev, dtype=odt)
+        run(shape, v, a, b, out, bias, None)
+        err = float((out[:300].float() - ref).abs().max())
+        tail = float((out[-1].float() - ((a[-1:].float() @ b.float().t() + bias) if epi != "gelu" else
+                                         (lambda r: r * torch.sigmoid(1.702 * r))(a[-1:].float() @ b.float().t() + bias))[0]).abs().max())
+        assert err < 0.06 and tail < 0.06, (name, v, err, tail)
+    times = {v: [] for v in VARIANTS}
+    out = torch.zeros(M, N, device=dev, dtype=odt)
+    for r in range(ROUNDS):
+        for v in VARIANTS:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run(shape, v, a, b, out, bias, None)
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 3)
+    line = f"{name} M={M:6d} N={N:5d} K={K:5d} {str(odt)[6:]:9s}"
+    for v in VARIANTS:
+        t = sorted(times[v])
+        med = t[len(t) // 2]
+        line += f" | v{v}: {med * 1e3:8.1f} us {flops / med / 1e9:7.1f} TF (min {t[0] * 1e3:.1f})"
+    print(line, flush=True)
