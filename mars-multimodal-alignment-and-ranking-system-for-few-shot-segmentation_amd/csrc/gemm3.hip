@@ -1,28 +1,50 @@
-// TN GEMM for the large-M products of the AlphaCLIP tower: 256 x 256 block tile, 8 waves
-// (2 x 4), each wave 128 x 64 outputs = 8 x 4 fragments of v_mfma_f32_16x16x32_bf16 (or four
-// v_mfma_f32_16x16x4_f32 per fragment pair for f32 inputs).
+// TN GEMM for the large-M products of the AlphaCLIP tower.  Block tile 256 x (64*NWC), 2 x NWC
+// waves, each wave 128 x 64 outputs = 8 x 4 fragments of v_mfma_f32_16x16x32_bf16 (or four
+// v_mfma_f32_16x16x4_f32 per fragment pair for f32 inputs).  Two shapes are built:
+//   NWC = 4: 256 x 256, 8 waves, 96 KiB LDS, one workgroup per CU;
+//   NWC = 2: 256 x 128, 4 waves, 72 KiB LDS, two workgroups per CU, so that one workgroup's
+//            epilogue (store-bound) runs beside the other's main loop (MFMA-bound) and a CU's
+//            share of the tiles is balanced at half-tile granularity.
 //
-// K is consumed in steps of 64 bytes per row (32 bf16 / 16 f32).  LDS holds a ring of four
-// steps (4 x (A 16 KiB + B 16 KiB) = 128 KiB, one workgroup per CU); the step three ahead is
-// fetched by LDS-DMA (global_load_lds, 1 KiB per wave instruction = 16 rows x 64 B) while the
-// current one feeds the MFMAs, and the DMAs stay in flight across the per-step barrier:
+// K is consumed in steps of 64 bytes per row (32 bf16 / 16 f32).  LDS holds a ring of three
+// steps; a step is fetched by LDS-DMA (global_load_lds, 1 KiB per wave instruction = 16 rows x
+// 64 B) two steps before its fragments are read and three before they feed the MFMAs, and the
+// DMAs stay in flight across the per-step barrier:
 //
-//     top of step s:  s_waitcnt vmcnt(8)   this wave's DMAs of step s have landed (s+1, s+2 still flying)
-//                     s_barrier            => every wave's have, and everybody is done reading step s-1
-//                     issue DMAs of step s+3 into the slot step s-1 used
-//                     12 x ds_read_b128, 32 MFMAs
+//     top of step s:  s_waitcnt vmcnt(n)   this wave's DMAs of step s+1 have landed (s+2 still flying)
+//                     s_barrier            => every wave's have, and everybody is done reading step s
+//                     issue DMAs of step s+3 into the slot step s used
+//                     12 x ds_read_b128 of step s+1 into the idle fragment registers,
+//                     32 MFMAs on the fragments of step s (fetched one step earlier)
 //
 // Bank swizzle (rows are 64 B, four 16-B chunks): chunk c of row r sits at chunk slot
 // c ^ g((r >> 2) & 3), g = {0,3,2,1}; the DMA image is lane-linear, so the xor is applied to
 // the per-lane SOURCE address and again on the fragment reads.
+#include <type_traits>
 #include "common.h"
 #include "../../include/mars_hip.h"
 
+// Diagnostic builds (tools/diag_gemm.hip) define MARS_STAMPS and read per-wave clock stamps from a
+// buffer of their own; in the library build the macro expands to nothing.
+#ifdef MARS_STAMPS
+__device__ unsigned long long* mars_stamp_buf;
+#define MARS_STAMP(i)                                                                                   \
+    if (lane == 0) mars_stamp_buf[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#define MARS_STAMP_ID()                                                                                 \
+    if (lane == 0) {                                                                                    \
+        unsigned long long* sb = mars_stamp_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16; \
+        sb[14] = __builtin_amdgcn_s_memrealtime();                                                      \
+        sb[15] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+    }
+#else
+#define MARS_STAMP(i)
+#define MARS_STAMP_ID()
+#endif
+
 namespace {
 
-constexpr int BM = 256, BN = 256, STEP_B = 64;           // bytes of K per row and step
-constexpr int NWAVES = 8, THREADS = 512;
-constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES, RING = 4;
+constexpr int BM = 256, STEP_B = 64;                     // bytes of K per row and step
+constexpr int A_BYTES = BM * STEP_B, RING = 3;
 constexpr int FM = 8, FN = 4;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -62,14 +84,20 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
     }
 }
 
-template <typename TIN, typename TOUT>
-__global__ __launch_bounds__(THREADS) void gemm_tn_ring_kernel(MarsGemm g) {
+template <typename TIN, typename TOUT, int NWC>
+__global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(MarsGemm g) {
+    constexpr int BN = 64 * NWC, NWAVES = 2 * NWC;
+    constexpr int B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_PIECES = BM / 16 / NWAVES, B_PIECES = BN / 16 / NWAVES;   // 1-KiB DMAs per wave and step
+    constexpr int PIECES = A_PIECES + B_PIECES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / NWC, wc = wave % NWC;
     const int r16 = lane & 15, kq = lane >> 4;
+    MARS_STAMP_ID()
+    MARS_STAMP(0)
 
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     const int nwg = ntm * ntn;
@@ -90,28 +118,30 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_ring_kernel(MarsGemm g) {
     const unsigned char* Bb = (const unsigned char*)g.B + (z0 * g.sB0 + z1 * g.sB1) * (int64_t)sizeof(TIN);
     const int64_t lda_b = g.lda * (int64_t)sizeof(TIN), ldb_b = g.ldb * (int64_t)sizeof(TIN);
 
-    // DMA sources: instruction i (0,1) of this wave fills rows (i*8 + wave)*16 .. +15 of A and of B
-    const unsigned char* pa[2];
-    const unsigned char* pb[2];
+    // DMA sources: piece i of this wave fills rows (i*NWAVES + wave)*16 .. +15 of A (then of B)
+    const unsigned char* pa[A_PIECES];
+    const unsigned char* pb[B_PIECES];
     {
         const int lr = lane >> 2, ls = lane & 3;
         const int chunk = ls ^ gsw((lr >> 2) & 3);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = (i * NWAVES + wave) * 16 + lr;
-            int ga = row0 + r; ga = ga < g.M ? ga : g.M - 1;
-            int gb = col0 + r; gb = gb < g.N ? gb : g.N - 1;
+        for (int i = 0; i < A_PIECES; ++i) {
+            int ga = row0 + (i * NWAVES + wave) * 16 + lr; ga = ga < g.M ? ga : g.M - 1;
             pa[i] = Ab + ga * lda_b + (chunk << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) {
+            int gb = col0 + (i * NWAVES + wave) * 16 + lr; gb = gb < g.N ? gb : g.N - 1;
             pb[i] = Bb + gb * ldb_b + (chunk << 4);
         }
     }
-    auto issue = [&](int s) {
-        unsigned char* sa = lds + (s & (RING - 1)) * STAGE;
+    auto issue = [&](int s, int slot) {
+        unsigned char* sa = lds + slot * STAGE;
         const int64_t ko = (int64_t)s * STEP_B;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(pa[i] + ko, sa + (i * NWAVES + wave) * 1024);
+        for (int i = 0; i < A_PIECES; ++i) glds16(pa[i] + ko, sa + (i * NWAVES + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(pb[i] + ko, sa + A_BYTES + (i * NWAVES + wave) * 1024);
+        for (int i = 0; i < B_PIECES; ++i) glds16(pb[i] + ko, sa + A_BYTES + (i * NWAVES + wave) * 1024);
     };
 
     f32x4 acc[FM][FN];
@@ -121,105 +151,221 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_ring_kernel(MarsGemm g) {
         for (int n = 0; n < FN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ns = (int)(((int64_t)g.K * sizeof(TIN)) / STEP_B);
-    const int lane_off = r16 * STEP_B + ((kq ^ gsw((r16 >> 2) & 3)) << 4);
-    const unsigned a_off = wr * 128 * STEP_B + lane_off;
-    const unsigned b_off = A_BYTES + wc * 64 * STEP_B + lane_off;
+    // The MFMAs compute C^T fragments (B rows are the first operand), so a lane ends up with four
+    // consecutive COLUMNS of one row of C: accumulator [m][n][reg] is C[16m + r16][colmap(n, reg)],
+    // and the epilogue stores 16 bytes per lane straight from registers.  For 2-byte outputs the B
+    // rows are dealt to the fragment pair (2v, 2v+1) so that the pair gives a lane 8 consecutive
+    // columns: row index i of fragment n is column 32(n>>1) + 8(i>>2) + 4(n&1) + (i&3).
+    constexpr bool PERM = sizeof(TOUT) == 2;
+    auto frag_off = [&](int row) { return row * STEP_B + ((kq ^ gsw((row >> 2) & 3)) << 4); };
+    const unsigned a_off = wr * 128 * STEP_B + frag_off(r16);
+    const int brow = PERM ? 8 * (r16 >> 2) + (r16 & 3) : r16;          // fragment 0; fragment 1 is 4 / 16 rows on
+    const unsigned b_off0 = A_BYTES + wc * 64 * STEP_B + frag_off(brow);
+    const unsigned b_off1 = A_BYTES + wc * 64 * STEP_B + frag_off(brow + (PERM ? 4 : 16));
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)lds;
 
-    issue(0);
-    if (ns > 1) issue(1);
-    if (ns > 2) issue(2);
-    for (int s = 0; s < ns; ++s) {
-        // the 4 DMAs of step s are the oldest outstanding ones of this wave
-        if (s + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + 3 < ns) issue(s + 3);
-        // Fragment reads are inline asm on purpose: hipcc treats an in-flight LDS-DMA as a pending LDS
-        // write and would put s_waitcnt vmcnt(0) in front of any ds_read it can see, draining the ring.
-        const unsigned sbase = lds_base + (unsigned)((s & (RING - 1)) * STAGE);
-        const unsigned aa = sbase + a_off, ba = sbase + b_off;
-        uint4 fa[FM], fb[FN];
-        lds_read128<0>(fb[0], ba); lds_read128<1024>(fb[1], ba); lds_read128<2048>(fb[2], ba); lds_read128<3072>(fb[3], ba);
-        lds_read128<0>(fa[0], aa); lds_read128<1024>(fa[1], aa); lds_read128<2048>(fa[2], aa); lds_read128<3072>(fa[3], aa);
-        lds_read128<4096>(fa[4], aa); lds_read128<5120>(fa[5], aa); lds_read128<6144>(fa[6], aa); lds_read128<7168>(fa[7], aa);
-#define MARS_ROW(m, cnt)                                                                           \
-        asm volatile("s_waitcnt lgkmcnt(" #cnt ")" ::: "memory");                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        _Pragma("unroll") for (int n = 0; n < FN; ++n) mma_step<TIN>(acc[m][n], fa[m], fb[n]);
-        MARS_ROW(0, 7) MARS_ROW(1, 6) MARS_ROW(2, 5) MARS_ROW(3, 4)
-        MARS_ROW(4, 3) MARS_ROW(5, 2) MARS_ROW(6, 1) MARS_ROW(7, 0)
-#undef MARS_ROW
+    // ---- main loop: the fragments of step s+1 are read while the MFMAs of step s run ----
+    uint4 faA[FM], fbA[FN], faB[FM], fbB[FN];
+#define MARS_READ(FA, FB, slot_)                                                                     \
+    {                                                                                                 \
+        const unsigned sbase = lds_base + (unsigned)((slot_) * STAGE);                                \
+        const unsigned aa = sbase + a_off, ba0 = sbase + b_off0, ba1 = sbase + b_off1;                \
+        lds_read128<0>(FB[0], ba0); lds_read128<0>(FB[1], ba1); lds_read128<2048>(FB[2], ba0); lds_read128<2048>(FB[3], ba1); \
+        lds_read128<0>(FA[0], aa); lds_read128<1024>(FA[1], aa); lds_read128<2048>(FA[2], aa); lds_read128<3072>(FA[3], aa); \
+        lds_read128<4096>(FA[4], aa); lds_read128<5120>(FA[5], aa); lds_read128<6144>(FA[6], aa); lds_read128<7168>(FA[7], aa); \
     }
-    // all fragment reads are complete (their data fed the MFMAs); meet before the ring is reused
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define MARS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    // One step.  At its top the DMAs of steps s+1 and s+2 are this wave's outstanding ones; step
+    // s+1 must have landed (for every wave: barrier) before its fragments are fetched, and the same
+    // barrier says that everybody has the fragments of step s in registers, so its slot can take
+    // step s+3.  Fragment reads are inline asm on purpose: hipcc treats an in-flight LDS-DMA as a
+    // pending LDS write and would put s_waitcnt vmcnt(0) in front of any ds_read it can see,
+    // draining the ring.  `slot` is the ring slot of step s.
+#define MARS_PHASE(CA, CB, NA, NB, s_)                                                               \
+    {                                                                                                 \
+        const int nslot = slot + 1 == RING ? 0 : slot + 1;                                            \
+        if ((s_) + 1 < ns) {                                                                          \
+            if ((s_) + 2 < ns) MARS_WAIT_VM(PIECES);                                                  \
+            else MARS_WAIT_VM(0);                                                                     \
+            __builtin_amdgcn_s_barrier();                                                             \
+            asm volatile("" ::: "memory");                                                            \
+            if ((s_) + 3 < ns) issue((s_) + 3, slot);                                                 \
+            MARS_READ(NA, NB, nslot)                                                                  \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int m = 0; m < FM; ++m)                                                \
+            _Pragma("unroll") for (int n = 0; n < FN; ++n) mma_step<TIN>(acc[m][n], CB[n], CA[m]);     \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        slot = nslot;                                                                                 \
+    }
+
+    issue(0, 0);
+    if (ns > 1) issue(1, 1);
+    if (ns > 2) issue(2, 2);
+    if (ns > 2) MARS_WAIT_VM(2 * PIECES);
+    else if (ns > 1) MARS_WAIT_VM(PIECES);
+    else MARS_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    MARS_READ(faA, fbA, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MARS_STAMP(1)
+    int slot = 0;
+    for (int s = 0; s < ns; s += 2) {
+        MARS_PHASE(faA, fbA, faB, fbB, s)
+        if (s + 1 < ns) MARS_PHASE(faB, fbB, faA, fbA, s + 1)
+    }
+#undef MARS_PHASE
+#undef MARS_READ
+#undef MARS_WAIT_VM
+    MARS_STAMP(2)
+    // every wave is past its last fragment read before the ring is reused for the epilogue
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    MARS_STAMP(3)
 
-    // ---------------- epilogue through LDS: 32 rows of the wave's tile at a time ----------------
+    // ---------------- epilogue ----------------
+    // Wave tiles inside the matrix with 16-byte aligned rows store straight from the accumulators
+    // (one of three short branch-free variants: plain, QuickGELU, residual add).  Everything else -
+    // edge tiles, unaligned rows, erf GELU, activation together with a residual - goes through LDS
+    // in slabs of 32 rows and a per-element loop.
     constexpr bool FAST = sizeof(TIN) == 2;
-    constexpr int EP_LD = FN * 16 + 4;
-    static_assert(NWAVES * 32 * EP_LD * 4 <= RING * STAGE, "epilogue staging does not fit");
+    constexpr int NV = PERM ? 2 : 4, VW = PERM ? 8 : 4;     // 16-byte stores per fragment row, columns per store
     TOUT* Cb = (TOUT*)g.C + (z0 * g.sC0 + z1 * g.sC1);
     const float* Rb = g.residual ? g.residual + (z0 * g.sR0 + z1 * g.sR1) : nullptr;
-    float* ep = (float*)lds + wave * 32 * EP_LD;
     const int wrow0 = row0 + wr * 128, wcol0 = col0 + wc * 64;
-    const int ec = (lane & 15) * 4, er = lane >> 4;    // 16 four-column chunks per row, 4 rows per pass
-    const bool vec_out = (g.ldc % 4 == 0) && (((uintptr_t)Cb) % 16 == 0);
-    const bool vec_res = Rb && (g.ldr % 4 == 0) && (((uintptr_t)Rb) % 16 == 0);
-    const int col = wcol0 + ec;
-    const int nv = col < g.N ? (g.N - col >= 4 ? 4 : g.N - col) : 0;
-    float bias4[4], gam4[4];
+    const bool inside = wrow0 + 128 <= g.M && wcol0 + 64 <= g.N;
+    const bool aligned = (g.ldc % VW == 0) && (((uintptr_t)Cb) % 16 == 0) &&
+                         (!Rb || ((g.ldr % 4 == 0) && (((uintptr_t)Rb) % 16 == 0)));
+
+    auto fast = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;    // 0 plain, 1 QuickGELU, 2 residual add
+        const int lcol = wcol0 + VW * kq;                  // store v of a row starts at lcol + v * (64 / NV)
+        float bias_[NV][VW], gam_[NV][VW];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        bias4[e] = (g.bias && e < nv) ? g.bias[col + e] : 0.f;
-        gam4[e] = (g.gamma && e < nv) ? g.gamma[col + e] : 1.f;
-    }
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int half = 0; half < FM / 2; ++half) {
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int n = 0; n < FN; ++n)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ep[(mm * 16 + kq * 4 + j) * EP_LD + n * 16 + r16] = acc[half * 2 + mm][n][j];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int lr2 = it * 4 + er;
-            const int row = wrow0 + half * 32 + lr2;
-            if (row >= g.M || nv == 0) continue;
-            f32x4 v = *(const f32x4*)(ep + lr2 * EP_LD + ec);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_fn3<FAST>(g.alpha * v[e] + bias4[e], g.act) * gam4[e];
-            if (Rb) {
-                const float* rp = Rb + (int64_t)row * g.ldr + col;
-                if (vec_res && nv == 4) { const f32x4 r = *(const f32x4*)rp; v += r; }
-                else { for (int e = 0; e < nv; ++e) v[e] += rp[e]; }
+            for (int e = 0; e < VW; ++e) {
+                bias_[v][e] = g.bias ? g.bias[lcol + v * (64 / NV) + e] : 0.f;
+                gam_[v][e] = g.gamma ? g.gamma[lcol + v * (64 / NV) + e] : 1.f;
             }
-            TOUT* cp = Cb + (int64_t)row * g.ldc + col;
-            if (vec_out && nv == 4) {
-                if constexpr (sizeof(TOUT) == 4) *(f32x4*)cp = v;
-                else { bf16x4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3]; *(bf16x4*)cp = o; }
-            } else {
-                for (int e = 0; e < nv; ++e) st_from_f32<TOUT>(cp + e, v[e]);
-            }
+        TOUT* cp = Cb + (int64_t)(wrow0 + r16) * g.ldc + lcol;
+        // residual rows are requested PD - 1 fragment rows ahead of their use, in the registers the
+        // operand fragments no longer need; a load issued after a store would retire behind it
+        constexpr int PD = 3;
+        f32x4 res[PD][NV][VW / 4];
+        const float* rp = (MODE == 2) ? Rb + (int64_t)(wrow0 + r16) * g.ldr + lcol : nullptr;
+        auto load_res = [&](int m) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int q = 0; q < VW / 4; ++q)
+                    res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * (64 / NV) + 4 * q);
+        };
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int m = 0; m < PD - 1; ++m) load_res(m);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < FM; ++m) {
+            if constexpr (MODE == 2) {
+                if (m + PD - 1 < FM) load_res(m + PD - 1);
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float x[VW];
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    const float a0 = PERM ? acc[m][2 * v + (e >> 2)][e & 3] : acc[m][v][e & 3];
+                    float y = g.alpha * a0 + bias_[v][e];
+                    if constexpr (MODE == 1) y = act_fn3<FAST>(y, 2);
+                    y *= gam_[v][e];
+                    if constexpr (MODE == 2) y += res[m % PD][v][e >> 2][e & 3];
+                    x[e] = y;
+                }
+                TOUT* c = cp + (int64_t)m * 16 * g.ldc + v * (64 / NV);
+                if constexpr (sizeof(TOUT) == 4) {
+                    *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[e];
+                    *(bf16x8*)c = o;
+                }
+            }
+            if (m == 1) { MARS_STAMP(4) }
+            if (m == 3) { MARS_STAMP(5) }
+            if (m == 5) { MARS_STAMP(6) }
+            if (m == 7) { MARS_STAMP(7) }
+        }
+    };
+
+    if (inside && aligned && g.act == 0 && Rb) fast(std::integral_constant<int, 2>{});
+    else if (inside && aligned && g.act == 0 && !Rb) fast(std::integral_constant<int, 0>{});
+    else if (inside && aligned && g.act == 2 && !Rb) fast(std::integral_constant<int, 1>{});
+    else {
+        constexpr int EP_LD = FN * 16 + 4;
+        constexpr int CPL = 16 / (int)sizeof(TOUT), LPR = 64 / CPL, RPP = 64 / LPR, NPASS = 32 / RPP;
+        static_assert(NWAVES * 32 * EP_LD * 4 <= RING * STAGE, "epilogue staging does not fit");
+        float* ep = (float*)lds + wave * 32 * EP_LD;
+        const int ec = (lane % LPR) * CPL, er = lane / LPR;
+        const int col = wcol0 + ec;
+#pragma unroll
+        for (int half = 0; half < FM / 2; ++half) {
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int n = 0; n < FN; ++n) {
+                    const int c0 = PERM ? 32 * (n >> 1) + 8 * kq + 4 * (n & 1) : 16 * n + 4 * kq;
+                    *(f32x4*)(ep + (mm * 16 + r16) * EP_LD + c0) = acc[half * 2 + mm][n];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int it = 0; it < NPASS; ++it) {
+                const int lr2 = it * RPP + er;
+                const int row = wrow0 + half * 32 + lr2;
+                if (row >= g.M) continue;
+#pragma unroll 1
+                for (int e = 0; e < CPL; ++e) {
+                    const int c = col + e;
+                    if (c >= g.N) break;
+                    float x = g.alpha * ep[lr2 * EP_LD + ec + e] + (g.bias ? g.bias[c] : 0.f);
+                    x = act_fn3<false>(x, g.act) * (g.gamma ? g.gamma[c] : 1.f);
+                    if (Rb) x += Rb[(int64_t)row * g.ldr + c];
+                    st_from_f32<TOUT>(Cb + (int64_t)row * g.ldc + c, x);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MARS_STAMP(4 + half)
+        }
     }
+#ifdef MARS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MARS_STAMP(8)
+    if (lane == 0) mars_stamp_buf[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 }  // namespace
 
-void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s) {
-    dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(THREADS);
+template <int NWC>
+static void ring_launch(const MarsGemm& g, hipStream_t s) {
+    constexpr int BN = 64 * NWC;
+    dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(128 * NWC);
     if (g.in_dtype == 1) {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float>), grid, block, 0, s, g);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWC>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWC>), grid, block, 0, s, g);
     } else {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float>), grid, block, 0, s, g);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWC>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWC>), grid, block, 0, s, g);
     }
+}
+
+// wide = 256 x 256 tiles (one workgroup per CU), otherwise 256 x 128 (two per CU)
+void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, bool wide) {
+    if (wide) ring_launch<4>(g, s);
+    else ring_launch<2>(g, s);
 }

@@ -60,6 +60,37 @@ def test_gemm_epilogue(pkg, cuda, act):
     assert float((outb.float() - z).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 192), (513, 257, 64), (256, 512, 1024), (70, 1100, 320)])
+def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):
+    """Every kernel behind marship_gemm on ragged tiles, with the full epilogue, both output types."""
+    lib = pkg.hip.lib()
+    a = _rand((M, K), 11, cuda).to(dtype)
+    b = (_rand((N, K), 12, cuda) * 0.2).to(dtype)
+    bias, gamma = _rand((N,), 13, cuda), _rand((N,), 14, cuda)
+    res = _rand((M, N), 15, cuda)
+    z = 0.5 * (a.double() @ b.double().t()) + bias.double()
+    z = z * torch.sigmoid(1.702 * z)
+    old = lib.marship_set_gemm_variant(variant)
+    try:
+        out = res.clone()
+        pkg.ops.linear(a, b, out, bias=bias, gamma=gamma, residual=out, act=2, alpha=0.5)
+        # bf16 inputs take the fast exp / reciprocal in the QuickGELU of the ring kernels
+        tol = 2e-4 if dtype == torch.float32 else 2e-3
+        assert float((out.double() - (res.double() + gamma.double() * z)).abs().max()) < tol
+        outb = torch.full((M, N), float("nan"), device=cuda, dtype=torch.bfloat16)
+        pkg.ops.linear(a, b, outb, bias=bias, act=2, alpha=0.5)
+        assert float((outb.double() - z).abs().max()) < 0.06
+        # output rows wider than N keep their padding untouched (ldc > N, unaligned N)
+        wide = torch.full((M, N + 3), -7.0, device=cuda)
+        pkg.ops.linear(a, b, wide[:, :N])
+        assert float((wide[:, :N].double() - a.double() @ b.double().t()).abs().max()) < 2e-3
+        assert float((wide[:, N:] + 7.0).abs().max()) == 0.0
+    finally:
+        lib.marship_set_gemm_variant(old)
+
+
 def test_gemm_batched_strided(pkg, cuda):
     """The attention-shaped call: per (image, head) views into a packed qkv buffer."""
     B, H, T, D = 2, 3, 70, 192
