@@ -158,14 +158,15 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(MarsGemm g) {
 }  // namespace
 
 void mars_gemm_glds_launch(const MarsGemm& g, hipStream_t s, int variant);
-void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, bool wide);
+void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape);
 static int g_gemm_variant = 4;
 
 // Tuning hook: 0 = register-staged 128x128, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
-// 3 = LDS-DMA ring 256x256, 4 = choose by shape (default), 5 = LDS-DMA ring 256x128.
+// 3 = LDS-DMA ring 256x256, 4 = choose by shape (default), 5 = LDS-DMA ring 256x128,
+// 6 = LDS-DMA ring 128x128.
 extern "C" int marship_set_gemm_variant(int v) {
     const int old = g_gemm_variant;
-    if (v >= 0 && v <= 5) g_gemm_variant = v;
+    if (v >= 0 && v <= 6) g_gemm_variant = v;
     return old;
 }
 
@@ -187,12 +188,12 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     if (g_gemm_variant != 0) {
         int v = g_gemm_variant;
         if (v == 4) {
-            // the 256-row ring kernels need about a full wave of workgroups to pay off; of the two
-            // the 256x128 shape (two workgroups per CU) is the faster one on the tower's products
+            // the 256 x 128 ring shape needs about a full wave of workgroups to pay off; below that
+            // the 128 x 128 shape spreads the product over more CUs
             const int64_t big = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256) * g->nb0 * g->nb1;
-            v = big >= 192 ? 5 : 1;
+            v = big >= 192 ? 5 : 6;
         }
-        if (v == 3 || v == 5) mars_gemm_ring_launch(*g, s, v == 3);
+        if (v == 3 || v == 5 || v == 6) mars_gemm_ring_launch(*g, s, v == 3 ? 0 : v == 5 ? 1 : 2);
         else mars_gemm_glds_launch(*g, s, v);
         MARS_LAUNCH_CHECK();
         return 0;

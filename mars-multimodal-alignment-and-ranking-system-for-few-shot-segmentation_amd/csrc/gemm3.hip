@@ -43,9 +43,8 @@ __device__ unsigned long long* mars_stamp_buf;
 
 namespace {
 
-constexpr int BM = 256, STEP_B = 64;                     // bytes of K per row and step
-constexpr int A_BYTES = BM * STEP_B, RING = 3;
-constexpr int FM = 8, FN = 4;
+constexpr int STEP_B = 64;                               // bytes of K per row and step
+constexpr int RING = 3, FN = 4;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -84,10 +83,14 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
     }
 }
 
-template <typename TIN, typename TOUT, int NWC>
-__global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(MarsGemm g) {
-    constexpr int BN = 64 * NWC, NWAVES = 2 * NWC;
-    constexpr int B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
+// NWR x NWC waves, each FM x 4 fragments (16 FM x 64 outputs); WPE = waves per SIMD the register
+// budget must allow (workgroups per CU x waves per workgroup / 4).
+template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int WPE>
+__global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g) {
+    constexpr int BM = 16 * FM * NWR, BN = 64 * NWC, NWAVES = NWR * NWC;
+    constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
+    static_assert((BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0, "DMA pieces must divide among the waves");
+    static_assert(FM == 4 || FM == 8, "wave tile is 64 or 128 rows");
     constexpr int A_PIECES = BM / 16 / NWAVES, B_PIECES = BN / 16 / NWAVES;   // 1-KiB DMAs per wave and step
     constexpr int PIECES = A_PIECES + B_PIECES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE];
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
     // columns: row index i of fragment n is column 32(n>>1) + 8(i>>2) + 4(n&1) + (i&3).
     constexpr bool PERM = sizeof(TOUT) == 2;
     auto frag_off = [&](int row) { return row * STEP_B + ((kq ^ gsw((row >> 2) & 3)) << 4); };
-    const unsigned a_off = wr * 128 * STEP_B + frag_off(r16);
+    const unsigned a_off = wr * (16 * FM) * STEP_B + frag_off(r16);
     const int brow = PERM ? 8 * (r16 >> 2) + (r16 & 3) : r16;          // fragment 0; fragment 1 is 4 / 16 rows on
     const unsigned b_off0 = A_BYTES + wc * 64 * STEP_B + frag_off(brow);
     const unsigned b_off1 = A_BYTES + wc * 64 * STEP_B + frag_off(brow + (PERM ? 4 : 16));
@@ -166,14 +169,15 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
 
     // ---- main loop: the fragments of step s+1 are read while the MFMAs of step s run ----
     uint4 faA[FM], fbA[FN], faB[FM], fbB[FN];
-#define MARS_READ(FA, FB, slot_)                                                                     \
-    {                                                                                                 \
-        const unsigned sbase = lds_base + (unsigned)((slot_) * STAGE);                                \
-        const unsigned aa = sbase + a_off, ba0 = sbase + b_off0, ba1 = sbase + b_off1;                \
-        lds_read128<0>(FB[0], ba0); lds_read128<0>(FB[1], ba1); lds_read128<2048>(FB[2], ba0); lds_read128<2048>(FB[3], ba1); \
-        lds_read128<0>(FA[0], aa); lds_read128<1024>(FA[1], aa); lds_read128<2048>(FA[2], aa); lds_read128<3072>(FA[3], aa); \
-        lds_read128<4096>(FA[4], aa); lds_read128<5120>(FA[5], aa); lds_read128<6144>(FA[6], aa); lds_read128<7168>(FA[7], aa); \
-    }
+    auto read_frags = [&](uint4 (&FA)[FM], uint4 (&FB)[FN], int slot_) {
+        const unsigned sbase = lds_base + (unsigned)(slot_ * STAGE);
+        const unsigned aa = sbase + a_off, ba0 = sbase + b_off0, ba1 = sbase + b_off1;
+        lds_read128<0>(FB[0], ba0); lds_read128<0>(FB[1], ba1); lds_read128<2048>(FB[2], ba0); lds_read128<2048>(FB[3], ba1);
+        lds_read128<0>(FA[0], aa); lds_read128<1024>(FA[1], aa); lds_read128<2048>(FA[2], aa); lds_read128<3072>(FA[3], aa);
+        if constexpr (FM == 8) {
+            lds_read128<4096>(FA[4], aa); lds_read128<5120>(FA[5], aa); lds_read128<6144>(FA[6], aa); lds_read128<7168>(FA[7], aa);
+        }
+    };
 #define MARS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
     // One step.  At its top the DMAs of steps s+1 and s+2 are this wave's outstanding ones; step
     // s+1 must have landed (for every wave: barrier) before its fragments are fetched, and the same
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
             __builtin_amdgcn_s_barrier();                                                             \
             asm volatile("" ::: "memory");                                                            \
             if ((s_) + 3 < ns) issue((s_) + 3, slot);                                                 \
-            MARS_READ(NA, NB, nslot)                                                                  \
+            read_frags(NA, NB, nslot);                                                                \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         _Pragma("unroll") for (int m = 0; m < FM; ++m)                                                \
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
     else MARS_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    MARS_READ(faA, fbA, 0)
+    read_frags(faA, fbA, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     MARS_STAMP(1)
@@ -219,7 +223,6 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
         if (s + 1 < ns) MARS_PHASE(faB, fbB, faA, fbA, s + 1)
     }
 #undef MARS_PHASE
-#undef MARS_READ
 #undef MARS_WAIT_VM
     MARS_STAMP(2)
     // every wave is past its last fragment read before the ring is reused for the epilogue
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
     constexpr int NV = PERM ? 2 : 4, VW = PERM ? 8 : 4;     // 16-byte stores per fragment row, columns per store
     TOUT* Cb = (TOUT*)g.C + (z0 * g.sC0 + z1 * g.sC1);
     const float* Rb = g.residual ? g.residual + (z0 * g.sR0 + z1 * g.sR1) : nullptr;
-    const int wrow0 = row0 + wr * 128, wcol0 = col0 + wc * 64;
-    const bool inside = wrow0 + 128 <= g.M && wcol0 + 64 <= g.N;
+    const int wrow0 = row0 + wr * (16 * FM), wcol0 = col0 + wc * 64;
+    const bool inside = wcol0 + 64 <= g.N;       // rows beyond M are masked per lane in the fast variants
     const bool aligned = (g.ldc % VW == 0) && (((uintptr_t)Cb) % 16 == 0) &&
                          (!Rb || ((g.ldr % 4 == 0) && (((uintptr_t)Rb) % 16 == 0)));
 
@@ -258,12 +261,15 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
         constexpr int PD = 3;
         f32x4 res[PD][NV][VW / 4];
         const float* rp = (MODE == 2) ? Rb + (int64_t)(wrow0 + r16) * g.ldr + lcol : nullptr;
+        const int rows_left = g.M - (wrow0 + r16);         // fragment row m of this lane exists iff 16 m < rows_left
         auto load_res = [&](int m) {
+            if (16 * m < rows_left) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
+                for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int q = 0; q < VW / 4; ++q)
-                    res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * (64 / NV) + 4 * q);
+                    for (int q = 0; q < VW / 4; ++q)
+                        res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * (64 / NV) + 4 * q);
+            }
         };
         if constexpr (MODE == 2) {
 #pragma unroll
@@ -287,19 +293,21 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
                     x[e] = y;
                 }
                 TOUT* c = cp + (int64_t)m * 16 * g.ldc + v * (64 / NV);
-                if constexpr (sizeof(TOUT) == 4) {
-                    *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
-                } else {
-                    bf16x8 o;
+                if (16 * m < rows_left) {
+                    if constexpr (sizeof(TOUT) == 4) {
+                        *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
+                    } else {
+                        bf16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[e];
-                    *(bf16x8*)c = o;
+                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[e];
+                        *(bf16x8*)c = o;
+                    }
                 }
             }
-            if (m == 1) { MARS_STAMP(4) }
-            if (m == 3) { MARS_STAMP(5) }
-            if (m == 5) { MARS_STAMP(6) }
-            if (m == 7) { MARS_STAMP(7) }
+            if (m == FM / 4 - 1) { MARS_STAMP(4) }
+            if (m == FM / 2 - 1) { MARS_STAMP(5) }
+            if (m == 3 * FM / 4 - 1) { MARS_STAMP(6) }
+            if (m == FM - 1) { MARS_STAMP(7) }
         }
     };
 
@@ -351,21 +359,23 @@ __global__ __launch_bounds__(128 * NWC, 8 / (2 * NWC)) void gemm_tn_ring_kernel(
 
 }  // namespace
 
-template <int NWC>
+template <int NWR, int NWC, int FM, int WPE>
 static void ring_launch(const MarsGemm& g, hipStream_t s) {
-    constexpr int BN = 64 * NWC;
-    dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(128 * NWC);
+    constexpr int BM = 16 * FM * NWR, BN = 64 * NWC;
+    dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(64 * NWR * NWC);
     if (g.in_dtype == 1) {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWC>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWC>), grid, block, 0, s, g);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
     } else {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWC>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWC>), grid, block, 0, s, g);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
     }
 }
 
-// wide = 256 x 256 tiles (one workgroup per CU), otherwise 256 x 128 (two per CU)
-void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, bool wide) {
-    if (wide) ring_launch<4>(g, s);
-    else ring_launch<2>(g, s);
+// shape 0: 256 x 256 tiles (8 waves, one workgroup per CU); 1: 256 x 128 (4 waves, two per CU);
+// 2: 128 x 128 (4 waves of 64 x 64, three per CU) for products with few tiles
+void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape) {
+    if (shape == 0) ring_launch<2, 4, 8, 2>(g, s);
+    else if (shape == 1) ring_launch<2, 2, 8, 2>(g, s);
+    else ring_launch<2, 2, 4, 3>(g, s);
 }

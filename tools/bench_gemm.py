@@ -21,9 +21,15 @@ SHAPES = [
     ("aclip proj  ", 36928, 1024, 1024, torch.float32, "res"),
     ("aclip fc1   ", 36928, 4096, 1024, torch.bfloat16, "gelu"),
     ("aclip fc2   ", 36928, 1024, 4096, torch.float32, "res"),
-    ("dino  qkv   ", 1374, 3072, 1024, torch.bfloat16, "bias"),
-    ("dino  fc2   ", 1374, 1024, 4096, torch.float32, "res"),
+    ("dino  qkv   ", 2748, 3072, 1024, torch.bfloat16, "bias"),
+    ("dino  proj  ", 2748, 1024, 1024, torch.float32, "res"),
+    ("dino  fc1   ", 2748, 4096, 1024, torch.bfloat16, "gelu"),
+    ("dino  fc2   ", 2748, 1024, 4096, torch.float32, "res"),
+    ("clip  qkv   ", 1090, 2304, 768, torch.bfloat16, "bias"),
+    ("clip  fc2   ", 1090, 768, 3072, torch.float32, "res"),
     ("clip  fc1   ", 1090, 3072, 768, torch.bfloat16, "gelu"),
+    ("pir   f32   ", 1369, 1369, 1408, torch.float32, "f32"),
+    ("sim   f32   ", 1369, 1369, 1024, torch.float32, "f32"),
 ]
 
 
@@ -43,20 +49,25 @@ def run(shape, variant, a, b, out, bias, res):
 for shape in SHAPES:
     name, M, N, K, odt, epi = shape
     g = torch.Generator(device="cpu").manual_seed(0)
-    a = (torch.rand(M, K, generator=g) * 2 - 1).to(dev).to(torch.bfloat16)
-    b = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).to(dev).to(torch.bfloat16)
+    idt = torch.float32 if epi == "f32" else torch.bfloat16
+    a = (torch.rand(M, K, generator=g) * 2 - 1).to(dev).to(idt)
+    b = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).to(dev).to(idt)
     bias = torch.randn(N, generator=g).to(dev)
     flops = 2.0 * M * N * K
     # correctness of each variant on the first 300 rows
-    ref = a[:300].float() @ b.float().t() + bias
+    ref = a[:300].float() @ b.float().t() + (bias if epi != "f32" else 0)
+    if epi == "f32":
+        bias = None
     if epi == "gelu":
         ref = ref * torch.sigmoid(1.702 * ref)
     for v in VARIANTS:
         out = torch.zeros(M, N, device=dev, dtype=odt)
         run(shape, v, a, b, out, bias, None)
         err = float((out[:300].float() - ref).abs().max())
-        tail = float((out[-1].float() - ((a[-1:].float() @ b.float().t() + bias) if epi != "gelu" else
-                                         (lambda r: r * torch.sigmoid(1.702 * r))(a[-1:].float() @ b.float().t() + bias))[0]).abs().max())
+        last = a[-1:].float() @ b.float().t() + (bias if bias is not None else 0)
+        if epi == "gelu":
+            last = last * torch.sigmoid(1.702 * last)
+        tail = float((out[-1].float() - last[0]).abs().max())
         assert err < 0.06 and tail < 0.06, (name, v, err, tail)
     times = {v: [] for v in VARIANTS}
     out = torch.zeros(M, N, device=dev, dtype=odt)

@@ -1,6 +1,6 @@
 // Diagnostic build of the ring GEMM with per-wave clock stamps: where does a tile's time go?
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/diag_gemm.hip -o gpurun_out/diag_gemm
-//   diag_gemm M N K wide out_f32 residual [stagger_base stagger_per_step]
+//   diag_gemm M N K shape out_f32 residual
 // Stamps (shader cycles, per wave): 0 entry, 1 first fragments in registers, 2 main loop done,
 // 3 ring free, 4..7 epilogue slabs issued, 8 stores retired; 13/14 = 100 MHz wall clock at end/entry.
 #define MARS_STAMPS 1
@@ -15,12 +15,12 @@
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 36928, N = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 1024;
-    const bool wide = argc > 4 ? atoi(argv[4]) != 0 : false;
+    const int shape = argc > 4 ? atoi(argv[4]) : 1;   // 0: 256x256, 1: 256x128, 2: 128x128
     const bool out_f32 = argc > 5 ? atoi(argv[5]) != 0 : true;
     const bool resid = argc > 6 ? atoi(argv[6]) != 0 : true;
     
     
-    const int BN = wide ? 256 : 128, NW = wide ? 8 : 4;
+    const int BMt = shape == 2 ? 128 : 256, BN = shape == 0 ? 256 : 128, NW = shape == 0 ? 8 : 4;
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
     unsigned x = 12345u;
     for (auto& v : ha) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((x >> 9) & 0x3ffu) + ((x >> 3) & 0x8000u)); }
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&B, hb.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&bias, N * 4));
     CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(C, 0, (size_t)M * N * 4)); CK(hipMemset(bias, 0, N * 4));
-    const int nblk = ((M + 255) / 256) * ((N + BN - 1) / BN);
+    const int nblk = ((M + BMt - 1) / BMt) * ((N + BN - 1) / BN);
     unsigned long long* stamps; const size_t nst = (size_t)nblk * 8 * 16;
     CK(hipMalloc(&stamps, nst * 8)); CK(hipMemset(stamps, 0, nst * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(mars_stamp_buf), &stamps, sizeof(stamps)));
@@ -38,16 +38,16 @@ int main(int argc, char** argv) {
     g.in_dtype = 1; g.out_dtype = out_f32 ? 0 : 1; g.alpha = 1.f; g.bias = bias; g.act = out_f32 ? 0 : 2;
     if (resid) { g.residual = (const float*)C; g.ldr = N; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) mars_gemm_ring_launch(g, 0, wide);
+    for (int i = 0; i < 20; ++i) mars_gemm_ring_launch(g, 0, shape);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    mars_gemm_ring_launch(g, 0, wide);
+    mars_gemm_ring_launch(g, 0, shape);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h(nst);
     CK(hipMemcpy(h.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
-    printf("M=%d N=%d K=%d wide=%d f32=%d res=%d: %.1f us, %d blocks\n", M, N, K, wide, out_f32, resid, ms * 1e3, nblk);
+    printf("M=%d N=%d K=%d shape=%d f32=%d res=%d: %.1f us, %d blocks\n", M, N, K, shape, out_f32, resid, ms * 1e3, nblk);
     const char* names[9] = {"entry", "prologue", "mainloop", "ringfree", "slab0", "slab1", "slab2", "slab3", "retired"};
     for (int i = 1; i <= 8; ++i) {
         std::vector<double> d;
