@@ -10,8 +10,20 @@
 // k-step s, i.e. keys 32s + 4g + {0..3} and 32s + 16 + 4g + {0..3} for lane group g.
 // The A operand V^T[d][those keys] comes straight from the row-major V tile in LDS
 // through ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group, delivered column-wise).
+#include <type_traits>
 #include "common.h"
 #include "../../include/mars_hip.h"
+
+// Diagnostic builds (tools/diag_attn.hip) define MARS_STAMPS and collect per-wave cycle counts of
+// the three phases of a tile; in the library build the macros expand to nothing.
+#ifdef MARS_STAMPS
+__device__ unsigned long long* mars_attn_stamps;
+#define MARS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#define MARS_ACC(dst, a, b) dst += (b) - (a);
+#else
+#define MARS_T(var)
+#define MARS_ACC(dst, a, b)
+#endif
 
 namespace {
 
@@ -43,6 +55,13 @@ __device__ __forceinline__ bf16x8 load_vt_frag(const unsigned char* vt, int lane
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// Plain fmaxf: this file is built with IEEE mode off and NaNs not honoured (see the Makefile), so
+// hipcc does not put a NaN-quieting self-max in front of every maximum of an MFMA result.  Inline
+// asm is NOT an option for anything that reads MFMA results: the MFMA -> VALU read hazard is
+// covered by compiler-inserted wait states, and the compiler does not look inside asm statements.
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float vmax2(float a, float b) { return fmaxf(a, b); }
+
 // Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU:
 // v_permlane16_swap exchanges odd rows of its first operand with even rows of the second,
 // v_permlane32_swap the upper half of the first with the lower half of the second, so feeding
@@ -50,35 +69,38 @@ __device__ __forceinline__ bf16x8 load_vt_frag(const unsigned char* vt, int lane
 __device__ __forceinline__ float rows_max(float x) {
     unsigned u = __builtin_bit_cast(unsigned, x);
     auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    x = fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    x = vmax2(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
     u = __builtin_bit_cast(unsigned, x);
     r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    return vmax2(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
 }
-__device__ __forceinline__ float rows_sum(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    x = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    u = __builtin_bit_cast(unsigned, x);
-    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // QB query blocks of 16 per wave, NW waves per workgroup: one K/V tile in LDS serves NW*QB*16
 // queries, and a wave re-uses its K and V^T fragments (held in registers) for all its QB blocks,
 // which is what takes the LDS read traffic off the critical path.
+//
+// K/V tiles are double buffered and filled by LDS-DMA (global_load_lds, 1 KiB = 8 key rows per
+// wave instruction; the bank swizzle is applied to the per-lane source address).  Per tile: read
+// the tile's fragments into registers, then start the DMA of the next tile into the other buffer,
+// compute, and only then wait for the DMA and meet at the barrier - the fill has the whole
+// compute phase to land and no LDS read is ever issued while a DMA is in flight.
 template <int QB, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ O,
                                                              float* __restrict__ lse, int T, int H, int causal) {
-    constexpr int THREADS = NW * 64, QPB = NW * QB * 16, CPT = 512 / THREADS;  // chunks per thread, tile and operand
+    constexpr int QPB = NW * QB * 16, PPW = 16 / NW;        // queries per workgroup; DMA pieces per wave and tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KT * ROWB];  // [buf][K|V]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r16 = lane & 15;
     const int D = H * 64;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     const int q0 = blockIdx.x * QPB + wave * (QB * 16);
     const int64_t row_b = (int64_t)3 * D * 2;  // bytes per token row of qkv
     const unsigned char* base = (const unsigned char*)qkv + (int64_t)b * T * row_b + (int64_t)h * 128;
+    const bool wave_active = q0 < T;            // trailing waves of the last workgroup only help with the fills
 
     // Q^T operands: lane = query r16 of block qb, d = 8g + j (+32 for the second k-step)
     bf16x8 qf[QB][2];
@@ -90,119 +112,171 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const __bf16* __
         qf[qb][1] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 + 16 * g));
     }
 
-    const unsigned char* kp[CPT]; const unsigned char* vp[CPT]; int dst[CPT]; int srow[CPT];
+    // DMA piece i of this wave: piece index p = wave * PPW + i, operand p >> 3 (K, V), key rows 8 (p & 7) .. +7;
+    // lane -> key row (lane >> 3) of the piece, 16-byte slot lane & 7 holding chunk slot ^ ((row >> 1) & 7)
+    const unsigned char* psrc[PPW];
+    int prow[PPW];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const int qd = tid + THREADS * i;
-        srow[i] = qd >> 3;
-        const int c = qd & 7;
-        kp[i] = base + (int64_t)D * 2 + c * 16;
-        vp[i] = base + (int64_t)D * 4 + c * 16;
-        dst[i] = tile_off(srow[i], c);
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave * PPW + i;
+        prow[i] = 8 * (p & 7) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((prow[i] >> 1) & 7);
+        psrc[i] = base + (int64_t)D * 2 * (1 + (p >> 3)) + chunk * 16;
     }
-    const int nt = (T + KT - 1) / KT;
-    uint4 rk[CPT], rv[CPT];
-    auto gload = [&](int t) {
+    auto issue_tile = [&](int t, int buf) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int key = min(t * KT + srow[i], T - 1);
-            rk[i] = *(const uint4*)(kp[i] + (int64_t)key * row_b);
-            rv[i] = *(const uint4*)(vp[i] + (int64_t)key * row_b);
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i;
+            const int key = min(t * KT + prow[i], T - 1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(psrc[i] + (int64_t)key * row_b),
+                                             (lds_ptr_t)(&lds[buf][p >> 3][(p & 7) * 1024]), 16, 0, 0);
         }
     };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) { *(uint4*)(&lds[buf][0][dst[i]]) = rk[i]; *(uint4*)(&lds[buf][1][dst[i]]) = rv[i]; }
-    };
 
-    f32x4 o[QB][4];
-    float mrun[QB], lrun[QB];   // running max of s*c and sum of 2^(s*c - max), c = log2(e)/8
+    // o[qb][0..3]: un-normalised output, d blocks of 16; o[qb][4]: the same product against a block
+    // of ones, i.e. the running sum of the (bf16-rounded) probabilities, in all four registers
+    f32x4 o[QB][5];
+    float mrun[QB];             // running max of s*c, c = log2(e)/8
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        mrun[qb] = -INFINITY; lrun[qb] = 0.f;
+        mrun[qb] = -INFINITY;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) o[qb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 5; ++m) o[qb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const float c2 = 0.125f * 1.44269504088896340736f;
-
+    const int nt = (T + KT - 1) / KT;
     // causal: tiles past the last query of this workgroup are never needed
     const int nt_eff = causal ? min(nt, (blockIdx.x * QPB + QPB - 1) / KT + 1) : nt;
-    gload(0); swrite(0);
-    __syncthreads();
-    for (int t = 0; t < nt_eff; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt_eff) gload(t + 1);
-        const unsigned char* kt_ = &lds[buf][0][0];
-        const unsigned char* vt_ = &lds[buf][1][0];
-        bf16x8 kf[4][2], vf[4][2];
+
+    bf16x8 kf[4][2], vf[4][2];
+    // One key tile against the wave's query blocks (straight-line code over the blocks, so that one
+    // block's MFMAs can be scheduled beside the other's VALU work).  MASKED tiles (ragged last
+    // tile, causal) skip the fragments that hold no valid key at all.
+    auto process = [&](int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int nfrag = MASKED ? min(4, (T - t * KT + 15) >> 4) : 4;     // fragments with a key < T
+        f32x4 s[QB][4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            kf[f][0] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, g)));
-            kf[f][1] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, 4 + g)));
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { vf[m][0] = load_vt_frag(vt_, lane, m, 0); vf[m][1] = load_vt_frag(vt_, lane, m, 1); }
-        const bool need_mask = (t * KT + KT > T) || causal;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            f32x4 s[4];
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][0], qf[qb][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][1], qf[qb][1], acc, 0, 0, 0);
-                s[f] = acc;
+                if (!MASKED || f < nfrag) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][0], qf[qb][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][1], qf[qb][1], acc, 0, 0, 0);
+                    s[qb][f] = acc;
+                } else {
+                    s[qb][f] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
             }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
             // lane holds keys t*64 + 16f + 4g + j of query q0 + 16qb + r16
-            if (need_mask) {
+            if constexpr (MASKED) {
                 const int myq = q0 + qb * 16 + r16;
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int key = t * KT + 16 * f + 4 * g + j;
-                        if (key >= T || (causal && key > myq)) s[f][j] = -INFINITY;
+                        if (key >= T || (causal && key > myq)) s[qb][f][j] = -INFINITY;
                     }
             }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
+            float mx = vmax3(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
+            mx = vmax3(mx, s[qb][0][3], s[qb][1][0]);
+            mx = vmax3(mx, s[qb][1][1], s[qb][1][2]);
+            mx = vmax3(mx, s[qb][1][3], s[qb][2][0]);
+            mx = vmax3(mx, s[qb][2][1], s[qb][2][2]);
+            mx = vmax3(mx, s[qb][2][3], s[qb][3][0]);
+            mx = vmax3(mx, s[qb][3][1], s[qb][3][2]);
+            mx = vmax2(mx, s[qb][3][3]);
             mx = rows_max(mx);
-            const float mnew = fmaxf(mrun[qb], mx * c2);
-            const bool dead = mnew == -INFINITY;                       // every key so far is masked
+            const float mnew = vmax2(mrun[qb], mx * c2);
+            const bool dead = MASKED && mnew == -INFINITY;                 // every key so far is masked
             const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(mrun[qb] - mnew);
-            float ps = 0.f;
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float p = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[f][j], c2, -mnew));
-                    s[f][j] = p;
-                    ps += p;
-                }
-            ps = rows_sum(ps);
-            lrun[qb] = lrun[qb] * alpha + ps;
             mrun[qb] = mnew;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (!MASKED || f < nfrag) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        s[qb][f][j] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[qb][f][j], c2, -mnew));
+                } else {
+                    s[qb][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
             if (!__all(alpha == 1.f)) {   // the running max moved for some query of this block
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { o[qb][m][0] *= alpha; o[qb][m][1] *= alpha; o[qb][m][2] *= alpha; o[qb][m][3] *= alpha; }
+                for (int m = 0; m < 5; ++m) { o[qb][m][0] *= alpha; o[qb][m][1] *= alpha; o[qb][m][2] *= alpha; o[qb][m][3] *= alpha; }
             }
-            const bf16x8 p0 = pack_bf16x8(s[0], s[1]);
-            const bf16x8 p1 = pack_bf16x8(s[2], s[3]);
+            const bf16x8 p0 = pack_bf16x8(s[qb][0], s[qb][1]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][0], p0, o[qb][m], 0, 0, 0);
-                o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][1], p1, o[qb][m], 0, 0, 0);
+            for (int m = 0; m < 4; ++m) o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][0], p0, o[qb][m], 0, 0, 0);
+            o[qb][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, o[qb][4], 0, 0, 0);
+            if (!MASKED || nfrag > 2) {
+                const bf16x8 p1 = pack_bf16x8(s[qb][2], s[qb][3]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][1], p1, o[qb][m], 0, 0, 0);
+                o[qb][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, o[qb][4], 0, 0, 0);
             }
         }
-        if (t + 1 < nt_eff) swrite(buf ^ 1);
+    };
+
+#ifdef MARS_STAMPS
+    unsigned long long c_read = 0, c_comp = 0, c_wait = 0;
+#endif
+    MARS_T(ts0)
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    MARS_T(ts1)
+    for (int t = 0; t < nt_eff; ++t) {
+        const int buf = t & 1;
+        MARS_T(ta)
+        if (wave_active) {
+            const unsigned char* kt_ = &lds[buf][0][0];
+            const unsigned char* vt_ = &lds[buf][1][0];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                kf[f][0] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, g)));
+                kf[f][1] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt_ + tile_off(16 * f + r16, 4 + g)));
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { vf[m][0] = load_vt_frag(vt_, lane, m, 0); vf[m][1] = load_vt_frag(vt_, lane, m, 1); }
+        }
+        // the fragments are in registers before the next fill starts: hipcc drains every in-flight
+        // LDS-DMA (vmcnt(0)) in front of an LDS read that follows one
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MARS_T(tb)
+        if (t + 1 < nt_eff) issue_tile(t + 1, buf ^ 1);
+        if (wave_active) {
+            if ((t * KT + KT > T) || causal) process(t, std::true_type{});
+            else process(t, std::false_type{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MARS_T(tc)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        MARS_T(td)
+        MARS_ACC(c_read, ta, tb) MARS_ACC(c_comp, tb, tc) MARS_ACC(c_wait, tc, td)
     }
+#ifdef MARS_STAMPS
+    if (lane == 0) {
+        unsigned long long* sb = mars_attn_stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+        sb[0] = ts1 - ts0; sb[1] = c_read; sb[2] = c_comp; sb[3] = c_wait; sb[4] = __builtin_amdgcn_s_memtime() - ts0;
+        sb[5] = wave_active ? 1 : 0;
+    }
+#endif
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int myq = q0 + qb * 16 + r16;
         if (myq < T) {
-            const float inv = 1.0f / lrun[qb];
+            const float lsum = o[qb][4][0];
+            const float inv = 1.0f / lsum;
             __bf16* op = O + ((int64_t)b * T + myq) * D + h * 64;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -212,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const __bf16* __
                 *(bf16x4*)(op + 16 * m + 4 * g) = v;
             }
             // natural-log LSE of the scaled scores: (max + log2(sum)) * ln 2
-            if (lse && g == 0) lse[(int64_t)bh * T + myq] = (mrun[qb] + log2f(lrun[qb])) * 0.69314718055994530942f;
+            if (lse && g == 0) lse[(int64_t)bh * T + myq] = (mrun[qb] + log2f(lsum)) * 0.69314718055994530942f;
         }
     }
 }

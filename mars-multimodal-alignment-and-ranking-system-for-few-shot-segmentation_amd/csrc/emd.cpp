@@ -33,14 +33,23 @@ public:
     TransportSimplex(const double* C, int n, int m) : C_(C), n_(n), m_(m), N_(n + m) {}
 
     double solve() {
-        if (n_ <= 0 || m_ <= 0) return std::numeric_limits<double>::quiet_NaN();
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        if (n_ <= 0 || m_ <= 0) return nan;
+        // the pivoting below relies on ordered comparisons; a NaN or infinite cost would let it pick
+        // arcs that break the tree, so such a problem has no answer instead
+        for (int64_t e = 0; e < (int64_t)n_ * m_; ++e)
+            if (!std::isfinite(C_[e])) return nan;
         init_basis();
         const int64_t narcs = (int64_t)n_ * m_;
         int64_t block = (int64_t)std::sqrt((double)narcs);
         if (block < 16) block = 16;
         int64_t next = 0;  // arc where the next pricing block starts
         const double eps = 1e-11;
-        for (;;) {
+        // Orden's perturbation rules out degenerate pivots, so the count stays far below this cap;
+        // it only bounds the damage of an input that violates the solver's assumptions
+        const int64_t max_pivots = 64 * (int64_t)N_ * N_ + 100000;
+        for (int64_t pivots = 0;; ++pivots) {
+            if (pivots > max_pivots || broken_) return nan;
             // block pricing: most negative reduced cost inside the first block that has one
             int64_t best = -1;
             double best_rc = -eps;
@@ -149,6 +158,7 @@ private:
                 y = parent_[y];
             }
         }
+        if (leave < 0) { broken_ = true; return; }   // entering arc closed no cycle: not a spanning tree any more
         const int apex = x;
         for (x = a; x != apex; x = parent_[x]) flow_[x] += (x < n_) ? -theta : theta;
         for (y = b; y != apex; y = parent_[y]) flow_[y] += (y >= n_) ? -theta : theta;
@@ -185,6 +195,7 @@ private:
     }
 
     std::vector<int> path_, stack_;
+    bool broken_ = false;
 };
 
 }  // namespace

@@ -214,7 +214,9 @@ def test_flash_attention_matches_reference(pkg, cuda, B, T, H, causal):
         s = s + torch.full((T, T), float("-inf"), device=cuda).triu_(1)
     ref = torch.einsum("bhts,bshd->bthd", s.softmax(-1), q[:, :, 2]).reshape(B * T, D)
     assert float((O.float() - ref).abs().max()) < 3e-2
-    assert float((lse.view(B, H, T) - torch.logsumexp(s, -1)).abs().max()) < 1e-3
+    # the row sum is accumulated from the bf16-rounded probabilities (the same values the PV product
+    # uses), so the LSE carries their rounding: 2^-9 relative per term, a few 1e-3 in the worst row
+    assert float((lse.view(B, H, T) - torch.logsumexp(s, -1)).abs().max()) < 4e-3
     if not causal:
         off, Pn = 1, T - 1
         ld = (Pn + 63) // 64 * 64

@@ -64,3 +64,16 @@ def test_product_emd_scores_batch(pkg):
         assert abs(float(got[k]) - (1 - emd2_uniform(M))) < 1e-10
     got2 = ops.emd_scores_host(torch.from_numpy(C).contiguous(), fg, bits, threads=1, is_cost=True)
     assert float((got - got2).abs().max()) < 1e-12
+
+
+def test_product_simplex_rejects_non_finite_costs(pkg):
+    """A NaN or infinite cost has no transport optimum: the answer is NaN, promptly, instead of a
+    pivoting sequence on comparisons that no longer order anything."""
+    lib = pkg.hip.lib()
+    rng = np.random.default_rng(3)
+    for bad in (np.nan, np.inf, -np.inf):
+        M = np.ascontiguousarray(rng.random((30, 40)))
+        M[7, 11] = bad
+        assert np.isnan(lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), 30, 40))
+    M = np.full((12, 9), np.nan)
+    assert np.isnan(lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), 12, 9))
