@@ -182,6 +182,8 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     MARS_CHECK((g->sA0 * es) % 16 == 0 && (g->sA1 * es) % 16 == 0 && (g->sB0 * es) % 16 == 0 && (g->sB1 * es) % 16 == 0,
                "gemm: batch strides must keep 16-byte alignment");
     MARS_CHECK(g->lda >= g->K && g->ldb >= g->K && g->ldc >= 1, "gemm: leading dimension smaller than K");
+    // the tile-relative operand offsets (up to 256 rows) are 32-bit
+    MARS_CHECK(g->lda * es < (1 << 22) && g->ldb * es < (1 << 22), "gemm: lda/ldb rows longer than 4 MiB are not supported");
     const int ntm = (g->M + BM - 1) / BM, ntn = (g->N + BN - 1) / BN;
     dim3 grid(ntm * ntn, g->nb0 * g->nb1), block(THREADS);
     hipStream_t s = (hipStream_t)stream;

@@ -91,6 +91,22 @@ def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):
         lib.marship_set_gemm_variant(old)
 
 
+def test_gemm_large_m(pkg, cuda):
+    """Default launch policy on a tall product (the shape of the AlphaCLIP batch): in-place residual,
+    ragged last row tile, both output types."""
+    M, N, K = 36928, 1024, 128
+    a = _rand((M, K), 21, cuda).to(torch.bfloat16)
+    b = (_rand((N, K), 22, cuda) * 0.2).to(torch.bfloat16)
+    bias = _rand((N,), 23, cuda)
+    x = _rand((M, N), 24, cuda)
+    ref = x + (a.float() @ b.float().t() + bias)
+    pkg.ops.linear(a, b, x, bias=bias, residual=x)
+    assert float((x - ref).abs().max()) < 2e-3
+    out = torch.full((M, N), float("nan"), device=cuda, dtype=torch.bfloat16)
+    pkg.ops.linear(a, b, out, bias=bias)
+    assert float((out.float() - (ref - _rand((M, N), 24, cuda))).abs().max()) < 0.06
+
+
 def test_gemm_batched_strided(pkg, cuda):
     """The attention-shaped call: per (image, head) views into a packed qkv buffer."""
     B, H, T, D = 2, 3, 70, 192
