@@ -169,6 +169,16 @@ int marship_merge_masks(const float* masks, const uint8_t* keep, int N, int64_t 
 int marship_iou_counts(const float* pred, const float* gt, const float* ignore, int64_t HW,
                        float* counts, void* stream);
 
+/* Matched points inside each mask (matcher/Matcher.py:1167-1174,1200-1201): points are (x, y) in
+ * pixels, truncated and clipped to the image as the reference does; counts[k] = number of the K
+ * points whose pixel of mask k is non-zero.  masks [n, H, W] f32, points [K, 2] f32, counts int32 [n]. */
+int marship_points_in_masks(const float* masks, int n, int H, int W, const float* points, int K,
+                            int32_t* counts, void* stream);
+/* Prompt-similarity table (mars/ClipPipeline.py:165-168): out[i, p] = scale * cos(feats[i], text[p]);
+ * feats [N, E] (row stride ldf), text [P, E], out f32 [N, P]. */
+int marship_cosine_table(const float* feats, int64_t ldf, int N, int E, const float* text, int P,
+                         float scale, float* out, void* stream);
+
 /* ---- GradCAM backward pieces ----------------------------------------------------- */
 /* LayerNorm backward w.r.t. the input: dx = add + LN'(x)[dy*w].  dy row r is dy + r*dy_stride
  * (dy_stride 0 broadcasts one row); rows < skip_rows get dy = 0. */

@@ -11,7 +11,7 @@ name with the repository root on ``sys.path``).  Sub-modules:
   mars       MARS facade and its components (reference API surface)
   utils      BackboneLoader seam
 """
-from . import synth  # noqa: F401  (pure torch, always importable)
+from . import synth, tokenizer  # noqa: F401  (pure host code, always importable)
 
 __all__ = ["synth"]
 
@@ -20,5 +20,6 @@ def _load_native():
     """Import everything that needs the compiled library; raises if it is missing."""
     from . import hip  # noqa: F401
     hip.lib()  # raises a clear error when libmars_hip.so has not been built
-    from . import ops, models, mars, utils  # noqa: F401
+    from . import ops, models, mars, utils, matcher  # noqa: F401
+    from .mars import ClipPipeline  # noqa: F401
     return hip

@@ -554,6 +554,60 @@ extern "C" int marship_merge_masks(const float* masks, const uint8_t* keep, int 
     return 0;
 }
 
+// one block per mask; lanes stride over the points
+__global__ __launch_bounds__(256) void points_in_masks_kernel(const float* __restrict__ masks, int H, int W,
+                                                              const float* __restrict__ points, int K, int32_t* __restrict__ counts) {
+    const float* m = masks + (int64_t)blockIdx.x * H * W;
+    int c = 0;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        // astype(int64) truncates toward zero; then clip to the image
+        int x = (int)points[2 * i], y = (int)points[2 * i + 1];
+        x = min(max(x, 0), W - 1);
+        y = min(max(y, 0), H - 1);
+        c += m[(int64_t)y * W + x] != 0.f;
+    }
+    __shared__ float sm[8];
+    const float tot = block_reduce_sum((float)c, sm);      // exact: a count below 2^24
+    if (threadIdx.x == 0) counts[blockIdx.x] = (int32_t)tot;
+}
+
+// one wave per (row, prompt) pair: three dot products, f32 accumulation in lane-strided order
+__global__ __launch_bounds__(256) void cosine_table_kernel(const float* __restrict__ feats, int64_t ldf, int N, int E,
+                                                           const float* __restrict__ text, int P, float scale, float* __restrict__ out) {
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair >= N * P) return;
+    const int i = pair / P, p = pair % P;
+    const float* f = feats + (int64_t)i * ldf;
+    const float* t = text + (int64_t)p * E;
+    double ff = 0.0, tt = 0.0, ft = 0.0;
+    for (int e = lane; e < E; e += 64) {
+        const double a = f[e], b = t[e];
+        ff += a * a; tt += b * b; ft += a * b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ff += __shfl_xor(ff, o, 64); tt += __shfl_xor(tt, o, 64); ft += __shfl_xor(ft, o, 64); }
+    if (lane == 0) out[(int64_t)i * P + p] = (float)(scale * ft / (sqrt(ff) * sqrt(tt)));
+}
+
+extern "C" int marship_points_in_masks(const float* masks, int n, int H, int W, const float* points, int K, int32_t* counts,
+                                       void* stream) {
+    MARS_CHECK(masks && points && counts && n > 0 && H > 0 && W > 0 && K > 0, "points_in_masks: bad arguments");
+    hipLaunchKernelGGL(points_in_masks_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, masks, H, W, points, K, counts);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_cosine_table(const float* feats, int64_t ldf, int N, int E, const float* text, int P, float scale,
+                                    float* out, void* stream) {
+    MARS_CHECK(feats && text && out && N > 0 && E > 0 && P > 0 && ldf >= E, "cosine_table: bad arguments");
+    const int64_t pairs = (int64_t)N * P;
+    MARS_CHECK(pairs < (1ll << 30), "cosine_table: table too large");
+    hipLaunchKernelGGL(cosine_table_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feats, ldf, N, E,
+                       text, P, scale, out);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int marship_iou_counts(const float* pred, const float* gt, const float* ignore, int64_t HW, float* counts,
                                   void* stream) {
     MARS_CHECK(pred && gt && counts && HW > 0, "iou_counts: bad arguments");

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "marship_rank": [_P, _P, _P, _P, _P, _P, _I, _D, _D, _D, _P, _P, _P, _P],
     "marship_merge_masks": [_P, _P, _I, _L, _P, _P],
     "marship_iou_counts": [_P, _P, _P, _L, _P, _P],
+    "marship_points_in_masks": [_P, _I, _I, _I, _P, _I, _P, _P],
+    "marship_cosine_table": [_P, _L, _I, _I, _P, _I, _F, _P, _P],
     "marship_layernorm_bwd": [_P, _P, _P, _L, _F, _I, _P, _P, _I, _I, _F, _P],
     "marship_quickgelu_bwd": [_P, _P, _P, _L, _P],
     "marship_softmax_bwd": [_P, _P, _P, _L, _I, _I, _F, _P],

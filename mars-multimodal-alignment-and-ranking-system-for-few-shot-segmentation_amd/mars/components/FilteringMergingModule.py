@@ -33,7 +33,8 @@ class FilteringMergingModule:
         self.device = torch.device(device)
         self.alpha_clip_batch_size = 128
         if tokenizer is None:
-            from ...synth import tokenize as tokenizer
+            from ...tokenizer import default_tokenizer
+            tokenizer = default_tokenizer()   # merge-table BPE when MARS_BPE_PATH is set, else the bundled prompt ids
         self.tokenizer = tokenizer
         self.emd_threads = emd_threads or int(os.environ.get("MARS_EMD_THREADS", "0")) or min(16, os.cpu_count() or 1)
         self._mean = torch.tensor(CLIP_MEAN, dtype=torch.float32, device=self.device)

@@ -38,7 +38,8 @@ class VisualTextAlignmentModule:
             box_threshold=vta_refinement_box_threshold,
             last_n_attention_maps_for_refinement=last_n_attention_maps_for_refinement, device=device, num_regs=model_num_regs)
         if tokenizer is None:
-            from ...synth import tokenize as tokenizer
+            from ...tokenizer import default_tokenizer
+            tokenizer = default_tokenizer()   # merge-table BPE when MARS_BPE_PATH is set, else the bundled prompt ids
         self.tokenizer = tokenizer
         self._mean = torch.tensor(CLIP_MEAN, dtype=torch.float32, device=self.device)
         self._std = torch.tensor(CLIP_STD, dtype=torch.float32, device=self.device)

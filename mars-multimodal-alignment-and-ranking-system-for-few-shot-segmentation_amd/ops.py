@@ -335,6 +335,29 @@ def cosine_scores(feats: torch.Tensor, text: torch.Tensor, scores: torch.Tensor)
               "marship_cosine_scores")
 
 
+def cosine_table(feats: torch.Tensor, text: torch.Tensor, out: torch.Tensor, scale: float = 1.0):
+    """out[i, p] = scale * cos(feats[i], text[p])."""
+    _dev(feats, text, out)
+    _req(feats.dim() == 2 and text.dim() == 2 and feats.stride(1) == 1 and text.is_contiguous() and out.is_contiguous(), "cosine_table: layout")
+    _req(feats.dtype == torch.float32 and text.dtype == torch.float32 and out.dtype == torch.float32, "cosine_table: dtypes")
+    N, E = feats.shape
+    Pn = text.shape[0]
+    _req(text.shape[1] == E and out.numel() >= N * Pn, "cosine_table: sizes")
+    hip.check(hip.lib().marship_cosine_table(ptr(feats), feats.stride(0), N, E, ptr(text), Pn, float(scale), ptr(out), stream()),
+              "marship_cosine_table")
+
+
+def points_in_masks(masks: torch.Tensor, points: torch.Tensor, counts: torch.Tensor):
+    """counts[k] = number of (x, y) points whose pixel of mask k is set."""
+    _dev(masks, points, counts)
+    _req(masks.dim() == 3 and masks.is_contiguous() and masks.dtype == torch.float32, "points_in_masks: masks must be f32 [n,H,W]")
+    _req(points.dim() == 2 and points.shape[1] == 2 and points.is_contiguous() and points.dtype == torch.float32, "points_in_masks: points")
+    _req(counts.dtype == torch.int32 and counts.numel() >= masks.shape[0], "points_in_masks: counts")
+    n, H, W = masks.shape
+    hip.check(hip.lib().marship_points_in_masks(ptr(masks), n, H, W, ptr(points), points.shape[0], ptr(counts), stream()),
+              "marship_points_in_masks")
+
+
 def rank(emd, aclip, cnt, svv, svt, ucnt, N, alpha, sthr, dthr, score, order, keep):
     _dev(emd, aclip, cnt, svv, svt, ucnt, score, order, keep)
     _req(emd.dtype == torch.float64 and score.dtype == torch.float64 and order.dtype == torch.int32 and keep.dtype == torch.uint8,

@@ -20,6 +20,7 @@ for g in "$@"; do
         flash) run flash tests/test_gpu_kernels.py -k "flash" ;;
         models) run models tests/test_gpu_models.py ;;
         pipeline) run pipeline tests/test_gpu_pipeline.py ;;
+        shells) run shells tests/test_gpu_matcher_clip_pipeline.py ;;
     esac
 done
 exit 0
