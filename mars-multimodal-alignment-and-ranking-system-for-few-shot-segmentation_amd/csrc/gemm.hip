@@ -163,10 +163,10 @@ static int g_gemm_variant = 4;
 
 // Tuning hook: 0 = register-staged 128x128, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
 // 3 = LDS-DMA ring 256x256, 4 = choose by shape (default), 5 = LDS-DMA ring 256x128,
-// 6 = LDS-DMA ring 128x128.
+// 6 = LDS-DMA ring 128x128, 7 = LDS-DMA ring 64x128.
 extern "C" int marship_set_gemm_variant(int v) {
     const int old = g_gemm_variant;
-    if (v >= 0 && v <= 6) g_gemm_variant = v;
+    if (v >= 0 && v <= 7) g_gemm_variant = v;
     return old;
 }
 
@@ -194,8 +194,11 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
             // the 128 x 128 shape spreads the product over more CUs
             const int64_t big = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256) * g->nb0 * g->nb1;
             v = big >= 192 ? 5 : 6;
+            // fewer 128 x 128 tiles than about half the CUs: halve the tile height to spread the work
+            const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128) * g->nb0 * g->nb1;
+            if (v == 6 && t128 < 150) v = 7;
         }
-        if (v == 3 || v == 5 || v == 6) mars_gemm_ring_launch(*g, s, v == 3 ? 0 : v == 5 ? 1 : 2);
+        if (v == 3 || v >= 5) mars_gemm_ring_launch(*g, s, v == 3 ? 0 : v - 4);
         else mars_gemm_glds_launch(*g, s, v);
         MARS_LAUNCH_CHECK();
         return 0;

@@ -86,11 +86,11 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
 // NWR x NWC waves, each FM x 4 fragments (16 FM x 64 outputs); WPE = waves per SIMD the register
 // budget must allow (workgroups per CU x waves per workgroup / 4).
 template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int WPE>
-__global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g) {
+__global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g, int group_m) {
     constexpr int BM = 16 * FM * NWR, BN = 64 * NWC, NWAVES = NWR * NWC;
     constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
     static_assert((BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0, "DMA pieces must divide among the waves");
-    static_assert(FM == 4 || FM == 8, "wave tile is 64 or 128 rows");
+    static_assert(FM == 2 || FM == 4 || FM == 8, "wave tile is 32, 64 or 128 rows");
     constexpr int A_PIECES = BM / 16 / NWAVES, B_PIECES = BN / 16 / NWAVES;   // 1-KiB DMAs per wave and step
     constexpr int PIECES = A_PIECES + B_PIECES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE];
@@ -110,10 +110,9 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     // ... in a grouped raster, so the 32 tiles an XCD has in flight form a compact patch
-    constexpr int GROUP_M = 8;
-    const int gsize = GROUP_M * ntn;
-    const int first_m = (bid / gsize) * GROUP_M;
-    const int gm = min(ntm - first_m, GROUP_M);
+    const int gsize = group_m * ntn;
+    const int first_m = (bid / gsize) * group_m;
+    const int gm = min(ntm - first_m, group_m);
     const int tm = first_m + (bid % gsize) % gm, tn = (bid % gsize) / gm;
     const int row0 = tm * BM, col0 = tn * BN;
     const int z = blockIdx.y, z0 = z / g.nb1, z1 = z % g.nb1;
@@ -173,7 +172,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         const unsigned sbase = lds_base + (unsigned)(slot_ * STAGE);
         const unsigned aa = sbase + a_off, ba0 = sbase + b_off0, ba1 = sbase + b_off1;
         lds_read128<0>(FB[0], ba0); lds_read128<0>(FB[1], ba1); lds_read128<2048>(FB[2], ba0); lds_read128<2048>(FB[3], ba1);
-        lds_read128<0>(FA[0], aa); lds_read128<1024>(FA[1], aa); lds_read128<2048>(FA[2], aa); lds_read128<3072>(FA[3], aa);
+        lds_read128<0>(FA[0], aa); lds_read128<1024>(FA[1], aa);
+        if constexpr (FM >= 4) { lds_read128<2048>(FA[2], aa); lds_read128<3072>(FA[3], aa); }
         if constexpr (FM == 8) {
             lds_read128<4096>(FA[4], aa); lds_read128<5120>(FA[5], aa); lds_read128<6144>(FA[6], aa); lds_read128<7168>(FA[7], aa);
         }
@@ -359,23 +359,28 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
 
 }  // namespace
 
+// M-tiles per raster group (tuning knob of the diagnostic tools)
+int mars_ring_group_m = 8;
+
 template <int NWR, int NWC, int FM, int WPE>
 static void ring_launch(const MarsGemm& g, hipStream_t s) {
     constexpr int BM = 16 * FM * NWR, BN = 64 * NWC;
     dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(64 * NWR * NWC);
     if (g.in_dtype == 1) {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
     } else {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
     }
 }
 
 // shape 0: 256 x 256 tiles (8 waves, one workgroup per CU); 1: 256 x 128 (4 waves, two per CU);
-// 2: 128 x 128 (4 waves of 64 x 64, three per CU) for products with few tiles
+// 2: 128 x 128 (4 waves of 64 x 64, three per CU) for products with few tiles; 3: 64 x 128 (4 waves of
+// 32 x 64) for products that would not even give every CU a 128 x 128 tile
 void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape) {
     if (shape == 0) ring_launch<2, 4, 8, 2>(g, s);
     else if (shape == 1) ring_launch<2, 2, 8, 2>(g, s);
-    else ring_launch<2, 2, 4, 3>(g, s);
+    else if (shape == 2) ring_launch<2, 2, 4, 3>(g, s);
+    else ring_launch<2, 2, 2, 4>(g, s);
 }

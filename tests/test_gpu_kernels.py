@@ -60,7 +60,7 @@ def test_gemm_epilogue(pkg, cuda, act):
     assert float((outb.float() - z).abs().max()) < 0.05
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (513, 257, 64), (256, 512, 1024), (70, 1100, 320)])
 def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):

@@ -1,6 +1,6 @@
 // Diagnostic build of the ring GEMM with per-wave clock stamps: where does a tile's time go?
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/diag_gemm.hip -o gpurun_out/diag_gemm
-//   diag_gemm M N K shape out_f32 residual
+//   diag_gemm M N K shape out_f32 residual [group_m]
 // Stamps (shader cycles, per wave): 0 entry, 1 first fragments in registers, 2 main loop done,
 // 3 ring free, 4..7 epilogue slabs issued, 8 stores retired; 13/14 = 100 MHz wall clock at end/entry.
 #define MARS_STAMPS 1
@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     const bool resid = argc > 6 ? atoi(argv[6]) != 0 : true;
     
     
+    if (argc > 7) mars_ring_group_m = atoi(argv[7]);
     const int BMt = shape == 2 ? 128 : 256, BN = shape == 0 ? 256 : 128, NW = shape == 0 ? 8 : 4;
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
     unsigned x = 12345u;
