@@ -211,6 +211,117 @@ def clip_state_dict(cfg: ClipCfg, seed: int = 0, alpha: bool = False) -> Dict[st
 # ----------------------------------------------------------------------------
 # synthetic episodes
 # ----------------------------------------------------------------------------
+# Segment Anything (key layout of /root/reference/segment_anything/build_sam.py:47-106)
+# ----------------------------------------------------------------------------
+@dataclass(frozen=True)
+class SamCfg:
+    embed_dim: int
+    depth: int
+    num_heads: int
+    global_attn_indexes: Tuple[int, ...]
+    img_size: int = 1024
+    patch_size: int = 16
+    window_size: int = 14
+    out_chans: int = 256          # prompt / decoder embedding dim
+    dec_depth: int = 2
+    dec_heads: int = 8
+    dec_mlp_dim: int = 2048
+    iou_head_hidden: int = 256
+    iou_head_depth: int = 3
+    mask_in_chans: int = 16
+
+    def oracle_kw(self) -> dict:
+        return dict(img_size=self.img_size, patch=self.patch_size, depth=self.depth, heads=self.num_heads,
+                    window_size=self.window_size, global_attn_indexes=tuple(self.global_attn_indexes), use_rel_pos=True,
+                    dec_depth=self.dec_depth, dec_heads=self.dec_heads, iou_head_depth=self.iou_head_depth)
+
+
+SAM_ARCHS = {
+    "vit_h": SamCfg(1280, 32, 16, (7, 15, 23, 31)),
+    "vit_l": SamCfg(1024, 24, 16, (5, 11, 17, 23)),
+    "vit_b": SamCfg(768, 12, 12, (2, 5, 8, 11)),
+    # test-size models: a window that does not divide the token grid (padding), one global block
+    "tiny": SamCfg(64, 3, 2, (1,), img_size=128, window_size=3, out_chans=64, dec_heads=2, dec_mlp_dim=128, iou_head_hidden=64),
+    "tiny80": SamCfg(160, 2, 2, (1,), img_size=96, window_size=4, out_chans=64, dec_heads=4, dec_mlp_dim=96, iou_head_hidden=48),
+}
+
+
+def sam_state_dict(cfg: SamCfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
+    D, C, G = cfg.embed_dim, cfg.out_chans, cfg.img_size // cfg.patch_size
+    hd = D // cfg.num_heads
+    fan = 3 * cfg.patch_size ** 2
+    sd["image_encoder.patch_embed.proj.weight"] = randn(seed, "sam.pe.w", (D, 3, cfg.patch_size, cfg.patch_size), std=1.0 / math.sqrt(fan))
+    sd["image_encoder.patch_embed.proj.bias"] = randn(seed, "sam.pe.b", (D,), std=0.02)
+    sd["image_encoder.pos_embed"] = randn(seed, "sam.pos", (1, G, G, D), std=0.3)
+    for i in range(cfg.depth):
+        p = f"image_encoder.blocks.{i}"
+        size = G if i in cfg.global_attn_indexes else cfg.window_size
+        _norm(sd, seed, p + ".norm1", D)
+        _linear(sd, seed, p + ".attn.qkv", 3 * D, D, gain=1.5)
+        _linear(sd, seed, p + ".attn.proj", D, D)
+        sd[p + ".attn.rel_pos_h"] = randn(seed, p + ".rph", (2 * size - 1, hd), std=0.4 / math.sqrt(hd))
+        sd[p + ".attn.rel_pos_w"] = randn(seed, p + ".rpw", (2 * size - 1, hd), std=0.4 / math.sqrt(hd))
+        _norm(sd, seed, p + ".norm2", D)
+        _linear(sd, seed, p + ".mlp.lin1", 4 * D, D)
+        _linear(sd, seed, p + ".mlp.lin2", D, 4 * D)
+    sd["image_encoder.neck.0.weight"] = randn(seed, "sam.neck0", (C, D, 1, 1), std=1.0 / math.sqrt(D))
+    _norm(sd, seed, "image_encoder.neck.1", C)
+    sd["image_encoder.neck.2.weight"] = randn(seed, "sam.neck2", (C, C, 3, 3), std=1.0 / math.sqrt(9 * C))
+    _norm(sd, seed, "image_encoder.neck.3", C)
+    # prompt encoder
+    sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = randn(seed, "sam.pe_gauss", (2, C // 2), std=1.0)
+    for i in range(4):
+        sd[f"prompt_encoder.point_embeddings.{i}.weight"] = randn(seed, f"sam.pt{i}", (1, C), std=0.5)
+    sd["prompt_encoder.not_a_point_embed.weight"] = randn(seed, "sam.nap", (1, C), std=0.5)
+    sd["prompt_encoder.no_mask_embed.weight"] = randn(seed, "sam.nomask", (1, C), std=0.5)
+    mc = cfg.mask_in_chans
+    sd["prompt_encoder.mask_downscaling.0.weight"] = randn(seed, "sam.md0", (mc // 4, 1, 2, 2), std=0.5)
+    sd["prompt_encoder.mask_downscaling.0.bias"] = randn(seed, "sam.md0b", (mc // 4,), std=0.02)
+    _norm(sd, seed, "prompt_encoder.mask_downscaling.1", mc // 4)
+    sd["prompt_encoder.mask_downscaling.3.weight"] = randn(seed, "sam.md3", (mc, mc // 4, 2, 2), std=0.5 / math.sqrt(mc))
+    sd["prompt_encoder.mask_downscaling.3.bias"] = randn(seed, "sam.md3b", (mc,), std=0.02)
+    _norm(sd, seed, "prompt_encoder.mask_downscaling.4", mc)
+    sd["prompt_encoder.mask_downscaling.6.weight"] = randn(seed, "sam.md6", (C, mc, 1, 1), std=1.0 / math.sqrt(mc))
+    sd["prompt_encoder.mask_downscaling.6.bias"] = randn(seed, "sam.md6b", (C,), std=0.02)
+    # mask decoder
+    sd["mask_decoder.iou_token.weight"] = randn(seed, "sam.iou_tok", (1, C), std=0.5)
+    sd["mask_decoder.mask_tokens.weight"] = randn(seed, "sam.mask_tok", (4, C), std=0.5)
+
+    def attn(p, down):
+        inner = C // down
+        _linear(sd, seed, p + ".q_proj", inner, C, gain=1.5)
+        _linear(sd, seed, p + ".k_proj", inner, C, gain=1.5)
+        _linear(sd, seed, p + ".v_proj", inner, C)
+        _linear(sd, seed, p + ".out_proj", C, inner)
+    for i in range(cfg.dec_depth):
+        p = f"mask_decoder.transformer.layers.{i}"
+        attn(p + ".self_attn", 1)
+        attn(p + ".cross_attn_token_to_image", 2)
+        attn(p + ".cross_attn_image_to_token", 2)
+        for k in (1, 2, 3, 4):
+            _norm(sd, seed, f"{p}.norm{k}", C)
+        _linear(sd, seed, p + ".mlp.lin1", cfg.dec_mlp_dim, C)
+        _linear(sd, seed, p + ".mlp.lin2", C, cfg.dec_mlp_dim)
+    attn("mask_decoder.transformer.final_attn_token_to_image", 2)
+    _norm(sd, seed, "mask_decoder.transformer.norm_final_attn", C)
+    sd["mask_decoder.output_upscaling.0.weight"] = randn(seed, "sam.up0", (C, C // 4, 2, 2), std=1.0 / math.sqrt(C))
+    sd["mask_decoder.output_upscaling.0.bias"] = randn(seed, "sam.up0b", (C // 4,), std=0.02)
+    _norm(sd, seed, "mask_decoder.output_upscaling.1", C // 4)
+    sd["mask_decoder.output_upscaling.3.weight"] = randn(seed, "sam.up3", (C // 4, C // 8, 2, 2), std=1.0 / math.sqrt(C // 4))
+    sd["mask_decoder.output_upscaling.3.bias"] = randn(seed, "sam.up3b", (C // 8,), std=0.02)
+    for i in range(4):
+        p = f"mask_decoder.output_hypernetworks_mlps.{i}.layers"
+        _linear(sd, seed, p + ".0", C, C)
+        _linear(sd, seed, p + ".1", C, C)
+        _linear(sd, seed, p + ".2", C // 8, C)
+    dims = [C] + [cfg.iou_head_hidden] * (cfg.iou_head_depth - 1) + [4]
+    for j in range(cfg.iou_head_depth):
+        _linear(sd, seed, f"mask_decoder.iou_prediction_head.layers.{j}", dims[j + 1], dims[j])
+    return sd
+
+
+# ----------------------------------------------------------------------------
 def _box_blur(img: torch.Tensor, k: int = 9) -> torch.Tensor:
     pad = k // 2
     x = torch.nn.functional.pad(img[None], (pad, pad, pad, pad), mode="reflect")

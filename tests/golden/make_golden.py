@@ -228,6 +228,77 @@ def golden_evaluator(out):
     out["eval_union_ign"] = au2.numpy()
 
 
+def golden_sam(out):
+    """Segment Anything: the reference's own modules (segment_anything.modeling, utils.amg) on seeded
+    weights against oracle/sam.py."""
+    from functools import partial
+    # the package __init__ pulls the predictor (torchvision, absent); a bare package entry lets the
+    # torch-only sub-packages `modeling` and `utils.amg` import on their own
+    sa = types.ModuleType("segment_anything")
+    sa.__path__ = [os.path.join(REF, "segment_anything")]
+    sys.modules["segment_anything"] = sa
+    from segment_anything.modeling import ImageEncoderViT, MaskDecoder, PromptEncoder, Sam, TwoWayTransformer
+    from segment_anything.utils import amg
+    from oracle import sam as osam
+    for arch in ("tiny", "tiny80"):
+        cfg = synth.SAM_ARCHS[arch]
+        sd = synth.sam_state_dict(cfg, seed=5)
+        G = cfg.img_size // cfg.patch_size
+        model = Sam(
+            image_encoder=ImageEncoderViT(
+                depth=cfg.depth, embed_dim=cfg.embed_dim, img_size=cfg.img_size, mlp_ratio=4,
+                norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=cfg.num_heads, patch_size=cfg.patch_size,
+                qkv_bias=True, use_rel_pos=True, global_attn_indexes=cfg.global_attn_indexes, window_size=cfg.window_size,
+                out_chans=cfg.out_chans),
+            prompt_encoder=PromptEncoder(embed_dim=cfg.out_chans, image_embedding_size=(G, G),
+                                         input_image_size=(cfg.img_size, cfg.img_size), mask_in_chans=cfg.mask_in_chans),
+            mask_decoder=MaskDecoder(
+                num_multimask_outputs=3,
+                transformer=TwoWayTransformer(depth=cfg.dec_depth, embedding_dim=cfg.out_chans, mlp_dim=cfg.dec_mlp_dim,
+                                              num_heads=cfg.dec_heads),
+                transformer_dim=cfg.out_chans, iou_head_depth=cfg.iou_head_depth, iou_head_hidden_dim=cfg.iou_head_hidden),
+            pixel_mean=list(osam.PIXEL_MEAN), pixel_std=list(osam.PIXEL_STD))
+        model.load_state_dict(sd, strict=True)        # every parameter of the reference model is covered
+        model.eval()
+        kw = cfg.oracle_kw()
+        oh, ow = (100, 126) if arch == "tiny" else (96, 70)
+        img = (synth.rand(3, f"sam_img_{arch}", (oh, ow, 3)) * 255).to(torch.uint8).numpy()
+        inp = osam.apply_image(img, cfg.img_size)
+        t = torch.as_tensor(inp).permute(2, 0, 1).contiguous()[None].float()
+        print(f"[sam {arch}] input {inp.shape}")
+        with torch.no_grad():
+            ref_pre = model.preprocess(t)
+            ref_feat = model.image_encoder(ref_pre)
+        check("preprocess", ref_pre, osam.preprocess(t, cfg.img_size))
+        check("image_encoder", ref_feat, osam.image_encoder(sd, ref_pre, kw), tol=2e-5)
+        pts = torch.as_tensor(osam.apply_coords(osam.build_point_grid(3) * np.array([[ow, oh]]), (oh, ow), cfg.img_size))
+        labels = torch.ones(len(pts), 1, dtype=torch.int)
+        with torch.no_grad():
+            ref_sparse, ref_dense = model.prompt_encoder(points=(pts[:, None, :], labels), boxes=None, masks=None)
+            ref_pe = model.prompt_encoder.get_dense_pe()
+            ref_low, ref_iou = model.mask_decoder(image_embeddings=ref_feat, image_pe=ref_pe, sparse_prompt_embeddings=ref_sparse,
+                                                  dense_prompt_embeddings=ref_dense, multimask_output=True)
+            ref_masks = model.postprocess_masks(ref_low, tuple(t.shape[-2:]), (oh, ow))
+        check("sparse embeddings", ref_sparse, osam.embed_points(sd, pts[:, None, :].float(), labels.float(), (cfg.img_size, cfg.img_size)))
+        check("dense pe", ref_pe, osam.dense_pe(sd, (G, G)))
+        state = dict(features=ref_feat, input_size=tuple(t.shape[-2:]), original_size=(oh, ow))
+        o_masks, o_iou, o_low = osam.predict_torch(sd, kw, state, pts[:, None, :], labels)
+        check("low_res_masks", ref_low, o_low, tol=2e-5)
+        check("iou_predictions", ref_iou, o_iou, tol=2e-5)
+        check("masks (logits)", ref_masks, o_masks, tol=2e-5)
+        # amg helpers
+        m = ref_masks.flatten(0, 1)
+        check("stability score", amg.calculate_stability_score(m, 0.0, 1.0), osam.stability_score(m, 0.0, 1.0))
+        check("mask boxes", amg.batched_mask_to_box(m > 0), osam.mask_to_box(m > 0))
+        check("point grid", amg.build_point_grid(5), osam.build_point_grid(5))
+        out[f"sam_{arch}_image"] = img
+        out[f"sam_{arch}_features"] = ref_feat.numpy()
+        out[f"sam_{arch}_points"] = pts.numpy()
+        out[f"sam_{arch}_low_res"] = ref_low.numpy()
+        out[f"sam_{arch}_iou"] = ref_iou.numpy()
+        out[f"sam_{arch}_masks"] = ref_masks.numpy().astype(np.float32)
+
+
 def golden_tokens():
     _stub("ftfy", fix_text=lambda s: s)
     tk = _load_by_path("ref_simple_tokenizer", os.path.join(REF, "clip/simple_tokenizer.py"))
@@ -252,6 +323,7 @@ if __name__ == "__main__":
     golden_clip(out)
     golden_alphaclip(out)
     golden_evaluator(out)
+    golden_sam(out)
     golden_tokens()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"),

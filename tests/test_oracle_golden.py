@@ -83,3 +83,40 @@ def test_prompt_tokens_match_reference_tokenizer():
         row = synth.tokenize([text])[0]
         assert row[: len(ids)].tolist() == ids and int(row[len(ids):].abs().sum()) == 0
         assert int(row.argmax()) == len(ids) - 1   # EOT is the highest id: encode_text pools there
+
+
+@pytest.mark.parametrize("arch", ["tiny", "tiny80"])
+def test_sam_encoder_decoder_postprocess(arch):
+    """oracle/sam.py against the outputs of the reference's segment_anything.modeling modules."""
+    from oracle import sam as osam
+    cfg = synth.SAM_ARCHS[arch]
+    sd = synth.sam_state_dict(cfg, seed=5)
+    kw = cfg.oracle_kw()
+    img = G[f"sam_{arch}_image"]
+    state = osam.set_image(sd, kw, img)
+    assert maxdiff(state["features"], G[f"sam_{arch}_features"]) < 2e-5
+    pts = torch.as_tensor(G[f"sam_{arch}_points"])
+    masks, iou, low = osam.predict_torch(sd, kw, state, pts[:, None, :], torch.ones(len(pts), 1))
+    assert maxdiff(low, G[f"sam_{arch}_low_res"]) < 5e-5
+    assert maxdiff(iou, G[f"sam_{arch}_iou"]) < 5e-5
+    assert maxdiff(masks, G[f"sam_{arch}_masks"]) < 5e-5
+
+
+def test_sam_generator_structure():
+    """End-to-end generator of the oracle: record fields, NMS keeps non-overlapping boxes, thresholds bite."""
+    from oracle import sam as osam
+    cfg = synth.SAM_ARCHS["tiny"]
+    sd = synth.sam_state_dict(cfg, seed=5)
+    img = G["sam_tiny_image"]
+    recs = osam.generate(sd, cfg.oracle_kw(), img, points_per_side=4, points_per_batch=5, pred_iou_thresh=-10.0,
+                         stability_score_thresh=0.0, box_nms_thresh=0.7)
+    assert len(recs) >= 1
+    for r in recs:
+        assert r["segmentation"].shape == img.shape[:2] and r["segmentation"].dtype == bool
+        assert r["area"] == int(r["segmentation"].sum()) and len(r["bbox"]) == 4 and r["crop_box"] == [0, 0, img.shape[1], img.shape[0]]
+    none = osam.generate(sd, cfg.oracle_kw(), img, points_per_side=4, points_per_batch=16, pred_iou_thresh=10.0)
+    assert none == []
+    # NMS restatement on a hand-made case
+    boxes = torch.tensor([[0, 0, 10, 10], [1, 1, 10, 10], [20, 20, 30, 30], [0, 0, 9, 9.5]], dtype=torch.float32)
+    keep = osam.box_nms(boxes, torch.tensor([0.9, 0.95, 0.5, 0.1]), 0.7)
+    assert keep.tolist() == [1, 2]
