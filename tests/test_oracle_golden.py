@@ -4,9 +4,10 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
-from tests.helpers import GOLDEN, load_package
+from tests.helpers import GOLDEN, load_package, maxdiff
 from oracle import pipeline as opipe
 from oracle import vit as ovit
 
