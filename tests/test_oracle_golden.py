@@ -118,6 +118,6 @@ def test_sam_generator_structure():
     none = osam.generate(sd, cfg.oracle_kw(), img, points_per_side=4, points_per_batch=16, pred_iou_thresh=10.0)
     assert none == []
     # NMS restatement on a hand-made case
-    boxes = torch.tensor([[0, 0, 10, 10], [1, 1, 10, 10], [20, 20, 30, 30], [0, 0, 9, 9.5]], dtype=torch.float32)
+    boxes = torch.tensor([[0, 0, 10, 10], [1, 1, 10, 10], [20, 20, 30, 30], [0, 0, 9.9, 9.9]], dtype=torch.float32)
     keep = osam.box_nms(boxes, torch.tensor([0.9, 0.95, 0.5, 0.1]), 0.7)
     assert keep.tolist() == [1, 2]
