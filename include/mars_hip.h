@@ -38,7 +38,7 @@ typedef struct MarsGemm {
     const float* residual;           /* f32 [M,N] or NULL, added last */
     int64_t ldr, sR0, sR1;
     float alpha;                     /* applied to the accumulator first */
-    int32_t act;                     /* 0 none, 1 GELU(erf), 2 QuickGELU */
+    int32_t act;                     /* 0 none, 1 GELU(erf), 2 QuickGELU, 3 ReLU */
     int32_t in_dtype;                /* A and B: 0 f32, 1 bf16 */
     int32_t out_dtype;               /* C: 0 f32, 1 bf16 */
 } MarsGemm;
@@ -178,6 +178,47 @@ int marship_points_in_masks(const float* masks, int n, int H, int W, const float
  * feats [N, E] (row stride ldf), text [P, E], out f32 [N, P]. */
 int marship_cosine_table(const float* feats, int64_t ldf, int N, int E, const float* text, int P,
                          float scale, float* out, void* stream);
+
+/* ---- Segment-Anything proposal stage --------------------------------------------- */
+/* Row gather: dst[r, dst_col : dst_col+ncols] = idx[r] >= 0 ? src[idx[r], src_col : src_col+ncols] : 0.
+ * Window partition / un-partition with zero padding (segment_anything/modeling/image_encoder.py:243-289),
+ * 3x3 neighbourhoods of the neck convolution (:96-102) and the pixel shuffle of the transposed
+ * convolutions (mask_decoder.py:53-59) are all instances.  dtype 0 = f32, 1 = bf16 (same on both sides). */
+int marship_gather_rows(const void* src, int64_t ld_src, int src_col, const int32_t* idx, void* dst,
+                        int64_t ld_dst, int dst_col, int64_t rows, int ncols, int dtype, void* stream);
+/* Decomposed relative-position terms (image_encoder.py:325-361): q is read from the packed qkv
+ * buffer (row b*T+t, column head*hdp+d, d < hd); Rh [gh, Hk, hd] and Rw [gw, Wk, hd] are the
+ * get_rel_pos tables; rel_h [B*H, T, Hk], rel_w [B*H, T, Wk] f32. */
+int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd, int hdp, int gw,
+                        int Hk, int Wk, const float* Rh, const float* Rw, float* rel_h, float* rel_w,
+                        int dtype, void* stream);
+/* P[row, k] = softmax_k(S[row, k] + rel_h[row, k / Wk] + rel_w[row, k % Wk]) (image_encoder.py:357-359,236;
+ * without the bias terms: transformer.py:231-233), zeros in columns T..ldp-1.  Rows up to 16384 long. */
+int marship_softmax_bias_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t nrows, int T,
+                              const float* rel_h, const float* rel_w, int Hk, int Wk, int out_dtype,
+                              void* stream);
+/* Random-Fourier position code (prompt_encoder.py:185-192): coords [n, 2] in [0,1], G [2, F],
+ * out[i] = [sin(2 pi (2c-1).G), cos(...)] (2F values, row stride ldo).  With labels (int32 [n], may be
+ * NULL) the point-prompt rule of :86-90 is applied from table [3, 2F] = {not_a_point, negative,
+ * positive}: label -1 -> table[0]; 0 -> code + table[1]; 1 -> code + table[2]. */
+int marship_fourier_pe(const float* coords, const float* G, int F, const int32_t* labels,
+                       const float* table, float* out, int64_t ldo, int64_t n, void* stream);
+/* out[r, :] = a[r, :] + b[r % b_rows, :] (b may be NULL), f32 in, f32 or bf16 out: the "queries + pe"
+ * operands of the two-way transformer (transformer.py:158-178). */
+int marship_add_cast(const float* a, const float* b, int64_t b_rows, void* out, int64_t rows, int D,
+                     int out_dtype, void* stream);
+/* Elementwise activation with a type change (act 0 none, 1 GELU(erf), 3 ReLU): mask_decoder.py:56. */
+int marship_act_cast(const float* in, void* out, int64_t n, int act, int out_dtype, void* stream);
+/* Per mask of logits [n, H, W] (utils/amg.py:155-175, 310-353): out[k] = {#(> thr+off), #(> thr-off),
+ * x0, y0, x1, y1 of (> thr)} (int32 x 6; the box of an empty mask is 0,0,0,0). */
+int marship_mask_stats(const float* masks, int n, int H, int W, float thr, float off, int32_t* out,
+                       void* stream);
+/* out = in > thr ? 1 : 0 (automatic_mask_generator.py:440). */
+int marship_threshold_masks(const float* in, float thr, float* out, int64_t n, void* stream);
+/* Greedy box NMS for one category (torchvision batched_nms as called at automatic_mask_generator.py:370-376):
+ * host pointers; keep receives the surviving indices by decreasing score. */
+int marshost_box_nms(const float* boxes, const float* scores, int n, float iou_threshold, int32_t* keep,
+                     int32_t* nkeep);
 
 /* ---- GradCAM backward pieces ----------------------------------------------------- */
 /* LayerNorm backward w.r.t. the input: dx = add + LN'(x)[dy*w].  dy row r is dy + r*dy_stride

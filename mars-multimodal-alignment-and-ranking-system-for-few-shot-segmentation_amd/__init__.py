@@ -20,6 +20,6 @@ def _load_native():
     """Import everything that needs the compiled library; raises if it is missing."""
     from . import hip  # noqa: F401
     hip.lib()  # raises a clear error when libmars_hip.so has not been built
-    from . import ops, models, mars, utils, matcher  # noqa: F401
+    from . import ops, models, mars, utils, matcher, segment_anything  # noqa: F401
     from .mars import ClipPipeline  # noqa: F401
     return hip

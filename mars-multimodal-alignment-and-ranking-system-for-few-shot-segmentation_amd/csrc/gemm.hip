@@ -31,6 +31,7 @@ struct Epi {
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (act == 2) return v / (1.0f + expf(-1.702f * v));
+    if (act == 3) return fmaxf(v, 0.f);
     return v;
 }
 

@@ -22,6 +22,7 @@ constexpr int BKB = 128;  // bytes of K per tile row
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (act == 2) return v / (1.0f + expf(-1.702f * v));
+    if (act == 3) return fmaxf(v, 0.f);
     return v;
 }
 
@@ -38,7 +39,7 @@ __device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* 
 template <typename TIN, typename TOUT, int WM, int WN, int FM, int FN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(MarsGemm g) {
     constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
-    constexpr int NW = WM * WN, THREADS = NW * 64;
+    constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // 1-KiB DMA instructions per wave and tile
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");

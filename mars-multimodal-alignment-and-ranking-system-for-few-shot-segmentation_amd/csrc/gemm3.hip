@@ -61,6 +61,7 @@ __device__ __forceinline__ float act_fn3(float v, int act) {
         if constexpr (FAST) return v * __frcp_rn(1.0f + __expf(-1.702f * v));
         else return v / (1.0f + expf(-1.702f * v));
     }
+    if (act == 3) return fmaxf(v, 0.f);
     return v;
 }
 
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
 
     // ---------------- epilogue ----------------
     // Wave tiles inside the matrix with 16-byte aligned rows store straight from the accumulators
-    // (one of three short branch-free variants: plain, QuickGELU, residual add).  Everything else -
-    // edge tiles, unaligned rows, erf GELU, activation together with a residual - goes through LDS
+    // (short branch-free variants: plain, QuickGELU, erf GELU, ReLU, residual add).  Everything else -
+    // N-edge tiles, unaligned rows, an activation together with a residual - goes through LDS
     // in slabs of 32 rows and a per-element loop.
     constexpr bool FAST = sizeof(TIN) == 2;
     constexpr int NV = PERM ? 2 : 4, VW = PERM ? 8 : 4;     // 16-byte stores per fragment row, columns per store
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                          (!Rb || ((g.ldr % 4 == 0) && (((uintptr_t)Rb) % 16 == 0)));
 
     auto fast = [&](auto mode_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;    // 0 plain, 1 QuickGELU, 2 residual add
+        constexpr int MODE = decltype(mode_tag)::value;    // 0 plain, 1 QuickGELU, 2 residual add, 3 erf GELU, 4 ReLU
         const int lcol = wcol0 + VW * kq;                  // store v of a row starts at lcol + v * (64 / NV)
         float bias_[NV][VW], gam_[NV][VW];
 #pragma unroll
@@ -288,6 +289,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                     const float a0 = PERM ? acc[m][2 * v + (e >> 2)][e & 3] : acc[m][v][e & 3];
                     float y = g.alpha * a0 + bias_[v][e];
                     if constexpr (MODE == 1) y = act_fn3<FAST>(y, 2);
+                    if constexpr (MODE == 3) y = act_fn3<FAST>(y, 1);
+                    if constexpr (MODE == 4) y = fmaxf(y, 0.f);
                     y *= gam_[v][e];
                     if constexpr (MODE == 2) y += res[m % PD][v][e >> 2][e & 3];
                     x[e] = y;
@@ -314,6 +317,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     if (inside && aligned && g.act == 0 && Rb) fast(std::integral_constant<int, 2>{});
     else if (inside && aligned && g.act == 0 && !Rb) fast(std::integral_constant<int, 0>{});
     else if (inside && aligned && g.act == 2 && !Rb) fast(std::integral_constant<int, 1>{});
+    else if (inside && aligned && g.act == 1 && !Rb) fast(std::integral_constant<int, 3>{});
+    else if (inside && aligned && g.act == 3 && !Rb) fast(std::integral_constant<int, 4>{});
     else {
         constexpr int EP_LD = FN * 16 + 4;
         constexpr int CPL = 16 / (int)sizeof(TOUT), LPR = 64 / CPL, RPP = 64 / LPR, NPASS = 32 / RPP;

@@ -1,0 +1,248 @@
+// Kernels of the Segment-Anything proposal stage that the transformer kernels do not already cover:
+// row gathers (window partition / un-partition, 3x3 neighbourhoods, pixel shuffles), the decomposed
+// relative-position bias, a row softmax with that bias, the random-Fourier position code, and the
+// per-mask statistics of the automatic mask generator.
+#include "common.h"
+#include "../../include/mars_hip.h"
+
+namespace {
+
+// dst[r, 0:ncols] = idx[r] >= 0 ? src[idx[r], src_col : src_col + ncols] : 0   (elements of ES bytes)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, int64_t ld_src, int src_col,
+                                                          const int32_t* __restrict__ idx, T* __restrict__ dst, int64_t ld_dst,
+                                                          int dst_col, int64_t rows, int ncols) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int s = idx[r];
+    T* d = dst + r * ld_dst + dst_col;
+    if (s < 0) {
+        for (int c = lane; c < ncols; c += 64) d[c] = (T)0.f;
+    } else {
+        const T* p = src + (int64_t)s * ld_src + src_col;
+        for (int c = lane; c < ncols; c += 64) d[c] = p[c];
+    }
+}
+
+// rel_h[bh, t, kh] = q[bh, t, :] . Rh[qh(t), kh, :],  rel_w[bh, t, kw] = q[bh, t, :] . Rw[qw(t), kw, :]
+// q is read from the packed qkv buffer: row (b*T + t), column head*hdp + d.  One wave per (bh, t).
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_bias_kernel(const T* __restrict__ qkv, int64_t ld, int Tn, int H, int hd, int hdp,
+                                                          int gw, int Hk, int Wk, const float* __restrict__ Rh,
+                                                          const float* __restrict__ Rw, float* __restrict__ rel_h,
+                                                          float* __restrict__ rel_w, int64_t nrows) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // (b*H + head)*Tn + t
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int t = (int)(row % Tn);
+    const int64_t bh = row / Tn;
+    const int head = (int)(bh % H);
+    const int64_t b = bh / H;
+    const int qh = t / gw, qw = t % gw;
+    const T* q = qkv + (b * Tn + t) * ld + (int64_t)head * hdp;
+    for (int k = lane; k < Hk + Wk; k += 64) {
+        const float* r = k < Hk ? Rh + ((int64_t)qh * Hk + k) * hd : Rw + ((int64_t)qw * Wk + (k - Hk)) * hd;
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc = fmaf(ld_as_f32<T>(q + d), r[d], acc);
+        if (k < Hk) rel_h[row * Hk + k] = acc;
+        else rel_w[row * Wk + (k - Hk)] = acc;
+    }
+}
+
+// P[row, k] = softmax_k(S[row, k] + rel_h[row, k / Wk] + rel_w[row, k % Wk]) for k < T, 0 for T <= k < ldp.
+// One workgroup per row; the biased row is kept in LDS between the three passes.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void softmax_bias_rows_kernel(const float* __restrict__ S, int64_t lds_, TOUT* __restrict__ P,
+                                                                int64_t ldp, int T, const float* __restrict__ rel_h,
+                                                                const float* __restrict__ rel_w, int Hk, int Wk) {
+    extern __shared__ float rowbuf[];
+    __shared__ float sm[8];
+    const int64_t row = blockIdx.x;
+    const float* sr = S + row * lds_;
+    const float* rh = rel_h ? rel_h + row * Hk : nullptr;
+    const float* rw = rel_w ? rel_w + row * Wk : nullptr;
+    float mx = -INFINITY;
+    for (int k = threadIdx.x; k < T; k += 256) {
+        float v = sr[k];
+        if (rh) v = (v + rh[k / Wk]) + rw[k % Wk];      // the order of the reference's two additions
+        rowbuf[k] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = block_reduce_max(mx, sm);
+    float sum = 0.f;
+    for (int k = threadIdx.x; k < T; k += 256) {
+        const float e = expf(rowbuf[k] - mx);
+        rowbuf[k] = e;
+        sum += e;
+    }
+    sum = block_reduce_sum(sum, sm);
+    TOUT* pr = P + row * ldp;
+    for (int k = threadIdx.x; k < ldp; k += 256) st_from_f32<TOUT>(pr + k, k < T ? rowbuf[k] / sum : 0.f);
+}
+
+// out[i, :] = [sin(2 pi ((2c - 1) . G)), cos(...)] for coordinate pairs c in [0,1]^2.  With labels:
+// label -1 replaces the code by table row 0, labels 0 / 1 add table rows 1 / 2 (prompt_encoder.py:86-90).
+__global__ __launch_bounds__(256) void fourier_pe_kernel(const float* __restrict__ coords, const float* __restrict__ G, int F,
+                                                         const int32_t* __restrict__ labels, const float* __restrict__ table,
+                                                         float* __restrict__ out, int64_t ldo, int64_t n) {
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    const float x = 2.f * coords[2 * i] - 1.f, y = 2.f * coords[2 * i + 1] - 1.f;
+    const int lab = labels ? labels[i] : 2;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float v = x * G[f] + y * G[F + f];          // row vector times the [2, F] matrix
+        v = 2.f * 3.14159265358979323846f * v;
+        float sv = sinf(v), cv = cosf(v);
+        if (lab == -1) { sv = 0.f + table[f]; cv = 0.f + table[F + f]; }
+        else if (lab == 0 || lab == 1) { sv += table[(int64_t)(lab + 1) * 2 * F + f]; cv += table[(int64_t)(lab + 1) * 2 * F + F + f]; }
+        out[i * ldo + f] = sv;
+        out[i * ldo + F + f] = cv;
+    }
+}
+
+// out[r, :] = a[r, :] + b[r % b_rows, :]  (b may be null), written in the output type
+template <typename TOUT>
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t b_rows,
+                                                       TOUT* __restrict__ out, int64_t rows, int D) {
+    const int64_t total = rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = a[i];
+        if (b) v += b[((i / D) % b_rows) * D + i % D];
+        st_from_f32<TOUT>(out + i, v);
+    }
+}
+
+// elementwise activation (1 = erf GELU, 3 = ReLU) with a type change
+template <typename TOUT>
+__global__ __launch_bounds__(256) void act_cast_kernel(const float* __restrict__ in, TOUT* __restrict__ out, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = in[i];
+        if (act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (act == 3) v = fmaxf(v, 0.f);
+        st_from_f32<TOUT>(out + i, v);
+    }
+}
+
+// per mask: #(logit > thr + off), #(logit > thr - off), and the bounding box of (logit > thr)
+__global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict__ masks, int H, int W, float thr, float off,
+                                                         int32_t* __restrict__ out) {
+    __shared__ int sh[6][4];
+    const float* m = masks + (int64_t)blockIdx.x * H * W;
+    int hi = 0, lo = 0, x0 = W, y0 = H, x1 = -1, y1 = -1;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const float v = m[i];
+        hi += v > thr + off;
+        lo += v > thr - off;
+        if (v > thr) {
+            const int y = i / W, x = i % W;
+            x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64);
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wave] = hi; sh[1][wave] = lo; sh[2][wave] = x0; sh[3][wave] = y0; sh[4][wave] = x1; sh[5][wave] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t* o = out + (int64_t)blockIdx.x * 6;
+        o[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        o[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        const int bx0 = min(min(sh[2][0], sh[2][1]), min(sh[2][2], sh[2][3])), by0 = min(min(sh[3][0], sh[3][1]), min(sh[3][2], sh[3][3]));
+        const int bx1 = max(max(sh[4][0], sh[4][1]), max(sh[4][2], sh[4][3])), by1 = max(max(sh[5][0], sh[5][1]), max(sh[5][2], sh[5][3]));
+        const bool empty = bx1 < bx0 || by1 < by0;      // an empty mask has the box [0, 0, 0, 0]
+        o[2] = empty ? 0 : bx0; o[3] = empty ? 0 : by0; o[4] = empty ? 0 : bx1; o[5] = empty ? 0 : by1;
+    }
+}
+
+// bits[k, i] = masks[k, i] > thr  (as f32 0/1, the proposal format of the ranking path)
+__global__ __launch_bounds__(256) void threshold_masks_kernel(const float* __restrict__ in, float thr, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i] > thr ? 1.f : 0.f;
+}
+
+}  // namespace
+
+extern "C" int marship_gather_rows(const void* src, int64_t ld_src, int src_col, const int32_t* idx, void* dst, int64_t ld_dst,
+                                   int dst_col, int64_t rows, int ncols, int dtype, void* stream) {
+    MARS_CHECK(src && idx && dst && rows > 0 && ncols > 0 && src_col >= 0 && dst_col >= 0, "gather_rows: bad arguments");
+    MARS_CHECK(ld_src >= src_col + ncols && ld_dst >= dst_col + ncols, "gather_rows: columns exceed the row");
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == 1) hipLaunchKernelGGL(gather_rows_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)src, ld_src, src_col, idx, (__bf16*)dst, ld_dst, dst_col, rows, ncols);
+    else hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, ld_src, src_col, idx, (float*)dst, ld_dst, dst_col, rows, ncols);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd, int hdp, int gw, int Hk, int Wk,
+                                   const float* Rh, const float* Rw, float* rel_h, float* rel_w, int dtype, void* stream) {
+    MARS_CHECK(qkv && Rh && Rw && rel_h && rel_w, "relpos_bias: null pointer");
+    MARS_CHECK(B > 0 && T > 0 && H > 0 && hd > 0 && hdp >= hd && gw > 0 && T % gw == 0 && Hk > 0 && Wk > 0 && ld >= (int64_t)H * hdp,
+               "relpos_bias: bad shape");
+    const int64_t nrows = (int64_t)B * H * T;
+    dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
+    if (dtype == 1) hipLaunchKernelGGL(relpos_bias_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, ld, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nrows);
+    else hipLaunchKernelGGL(relpos_bias_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)qkv, ld, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nrows);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_softmax_bias_rows(const float* S, int64_t lds_, void* P, int64_t ldp, int64_t nrows, int T, const float* rel_h,
+                                         const float* rel_w, int Hk, int Wk, int out_dtype, void* stream) {
+    MARS_CHECK(S && P && nrows > 0 && T > 0 && lds_ >= T && ldp >= T, "softmax_bias_rows: bad shape");
+    MARS_CHECK(T <= 16384, "softmax_bias_rows: rows longer than 16384 are not supported");
+    MARS_CHECK((rel_h == nullptr) == (rel_w == nullptr), "softmax_bias_rows: both bias terms or none");
+    MARS_CHECK(!rel_h || (Hk > 0 && Wk > 0 && (int64_t)Hk * Wk == T), "softmax_bias_rows: Hk*Wk must equal T");
+    MARS_CHECK(nrows < (1ll << 31), "softmax_bias_rows: too many rows");
+    dim3 grid((unsigned)nrows), block(256);
+    const size_t shm = (size_t)T * sizeof(float);
+    if (out_dtype == 1) hipLaunchKernelGGL(softmax_bias_rows_kernel<__bf16>, grid, block, shm, (hipStream_t)stream, S, lds_, (__bf16*)P, ldp, T, rel_h, rel_w, Hk, Wk);
+    else hipLaunchKernelGGL(softmax_bias_rows_kernel<float>, grid, block, shm, (hipStream_t)stream, S, lds_, (float*)P, ldp, T, rel_h, rel_w, Hk, Wk);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_fourier_pe(const float* coords, const float* G, int F, const int32_t* labels, const float* table, float* out,
+                                  int64_t ldo, int64_t n, void* stream) {
+    MARS_CHECK(coords && G && out && F > 0 && n > 0 && ldo >= 2 * F && n < (1ll << 31), "fourier_pe: bad arguments");
+    MARS_CHECK(!labels || table, "fourier_pe: labels need the embedding table");
+    hipLaunchKernelGGL(fourier_pe_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, coords, G, F, labels, table, out, ldo, n);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+static unsigned blocks_for(int64_t n) { const int64_t b = (n + 255) / 256; return (unsigned)(b < 65536 ? b : 65536); }
+
+extern "C" int marship_add_cast(const float* a, const float* b, int64_t b_rows, void* out, int64_t rows, int D, int out_dtype, void* stream) {
+    MARS_CHECK(a && out && rows > 0 && D > 0 && (!b || b_rows > 0), "add_cast: bad arguments");
+    if (out_dtype == 1) hipLaunchKernelGGL(add_cast_kernel<__bf16>, dim3(blocks_for(rows * D)), dim3(256), 0, (hipStream_t)stream, a, b, b_rows, (__bf16*)out, rows, D);
+    else hipLaunchKernelGGL(add_cast_kernel<float>, dim3(blocks_for(rows * D)), dim3(256), 0, (hipStream_t)stream, a, b, b_rows, (float*)out, rows, D);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_act_cast(const float* in, void* out, int64_t n, int act, int out_dtype, void* stream) {
+    MARS_CHECK(in && out && n > 0 && (act == 0 || act == 1 || act == 3), "act_cast: bad arguments");
+    if (out_dtype == 1) hipLaunchKernelGGL(act_cast_kernel<__bf16>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, in, (__bf16*)out, n, act);
+    else hipLaunchKernelGGL(act_cast_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, in, (float*)out, n, act);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_mask_stats(const float* masks, int n, int H, int W, float thr, float off, int32_t* out, void* stream) {
+    MARS_CHECK(masks && out && n > 0 && H > 0 && W > 0, "mask_stats: bad arguments");
+    hipLaunchKernelGGL(mask_stats_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, masks, H, W, thr, off, out);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_threshold_masks(const float* in, float thr, float* out, int64_t n, void* stream) {
+    MARS_CHECK(in && out && n > 0, "threshold_masks: bad arguments");
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(threshold_masks_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, in, thr, out, n);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}

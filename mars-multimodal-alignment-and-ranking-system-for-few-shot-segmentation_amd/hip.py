@@ -64,6 +64,15 @@ _SIGNATURES = {
     "marship_merge_masks": [_P, _P, _I, _L, _P, _P],
     "marship_iou_counts": [_P, _P, _P, _L, _P, _P],
     "marship_points_in_masks": [_P, _I, _I, _I, _P, _I, _P, _P],
+    "marship_gather_rows": [_P, _L, _I, _P, _P, _L, _I, _L, _I, _I, _P],
+    "marship_relpos_bias": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "marship_softmax_bias_rows": [_P, _L, _P, _L, _L, _I, _P, _P, _I, _I, _I, _P],
+    "marship_fourier_pe": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
+    "marship_add_cast": [_P, _P, _L, _P, _L, _I, _I, _P],
+    "marship_act_cast": [_P, _P, _L, _I, _I, _P],
+    "marship_mask_stats": [_P, _I, _I, _I, _F, _F, _P, _P],
+    "marship_threshold_masks": [_P, _F, _P, _L, _P],
+    "marshost_box_nms": [_P, _P, _I, _F, _P, _P],
     "marship_cosine_table": [_P, _L, _I, _I, _P, _I, _F, _P, _P],
     "marship_layernorm_bwd": [_P, _P, _P, _L, _F, _I, _P, _P, _I, _I, _F, _P],
     "marship_quickgelu_bwd": [_P, _P, _P, _L, _P],

@@ -445,3 +445,100 @@ def emd_scores_host(S_host: torch.Tensor, fg_host: torch.Tensor, bits_host: torc
     hip.check(hip.lib().marshost_emd_scores(_vp(S_host.data_ptr()), S_host.stride(0), R, P, _vp(fg_host.data_ptr()),
                                             _vp(bits_host.data_ptr()), N, 1 if is_cost else 0, _vp(out.data_ptr()), threads), "marshost_emd_scores")
     return out
+
+
+# ---------------------------------------------------------------- Segment-Anything proposal stage
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor, *, src_col: int = 0, dst_col: int = 0, ncols: Optional[int] = None):
+    """dst[r, dst_col:dst_col+ncols] = src[idx[r], src_col:src_col+ncols], zeros where idx[r] < 0."""
+    _dev(src, idx, dst)
+    _req(src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1 and src.dtype == dst.dtype, "gather_rows: layout")
+    _req(src.dtype in (torch.float32, torch.bfloat16) and idx.dtype == torch.int32 and idx.is_contiguous(), "gather_rows: dtypes")
+    rows = idx.numel()
+    ncols = ncols if ncols is not None else min(src.shape[1] - src_col, dst.shape[1] - dst_col)
+    _req(rows <= dst.shape[0] and src_col + ncols <= src.shape[1] and dst_col + ncols <= dst.shape[1], "gather_rows: sizes")
+    hip.check(hip.lib().marship_gather_rows(ptr(src), src.stride(0), src_col, ptr(idx), ptr(dst), dst.stride(0), dst_col, rows, ncols,
+                                            dt(src), stream()), "marship_gather_rows")
+
+
+def relpos_bias(qkv: torch.Tensor, B: int, T: int, H: int, hd: int, hdp: int, gw: int, Rh: torch.Tensor, Rw: torch.Tensor,
+                rel_h: torch.Tensor, rel_w: torch.Tensor):
+    _dev(qkv, Rh, Rw, rel_h, rel_w)
+    _req(qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape[0] >= B * T, "relpos_bias: qkv")
+    _req(Rh.dtype == torch.float32 and Rw.dtype == torch.float32 and Rh.is_contiguous() and Rw.is_contiguous(), "relpos_bias: tables")
+    gh = T // gw
+    Hk, Wk = Rh.shape[1], Rw.shape[1]
+    _req(tuple(Rh.shape) == (gh, Hk, hd) and tuple(Rw.shape) == (gw, Wk, hd), "relpos_bias: table shapes")
+    _req(rel_h.dtype == torch.float32 and rel_w.dtype == torch.float32 and rel_h.numel() >= B * H * T * Hk and rel_w.numel() >= B * H * T * Wk,
+         "relpos_bias: outputs")
+    hip.check(hip.lib().marship_relpos_bias(ptr(qkv), qkv.stride(0), B, T, H, hd, hdp, gw, Hk, Wk, ptr(Rh), ptr(Rw), ptr(rel_h), ptr(rel_w),
+                                            dt(qkv), stream()), "marship_relpos_bias")
+
+
+def softmax_bias_rows(S: torch.Tensor, P: torch.Tensor, nrows: int, T: int, rel_h=None, rel_w=None, Hk: int = 0, Wk: int = 0):
+    _dev(S, P, rel_h, rel_w)
+    _req(S.dtype == torch.float32 and S.stride(-1) == 1 and P.stride(-1) == 1, "softmax_bias_rows: layout")
+    lds_, ldp = S.stride(-2), P.stride(-2)
+    _req((nrows - 1) * lds_ + T <= _avail(S) and nrows * ldp <= _avail(P), "softmax_bias_rows: overrun")
+    hip.check(hip.lib().marship_softmax_bias_rows(ptr(S), lds_, ptr(P), ldp, nrows, T, ptr(rel_h), ptr(rel_w), Hk, Wk, dt(P), stream()),
+              "marship_softmax_bias_rows")
+
+
+def fourier_pe(coords: torch.Tensor, G: torch.Tensor, out: torch.Tensor, labels: Optional[torch.Tensor] = None,
+               table: Optional[torch.Tensor] = None):
+    """out [n, 2F] from coords [n, 2] in [0,1]; with labels the point-prompt embedding rule (see the header)."""
+    _dev(coords, G, out, labels, table)
+    _req(coords.dtype == torch.float32 and coords.is_contiguous() and coords.shape[-1] == 2, "fourier_pe: coords")
+    _req(G.dtype == torch.float32 and G.is_contiguous() and G.shape[0] == 2 and out.dtype == torch.float32 and out.is_contiguous(), "fourier_pe: G/out")
+    n, F_ = coords.numel() // 2, G.shape[1]
+    _req(out.numel() >= n * 2 * F_, "fourier_pe: out size")
+    if labels is not None:
+        _req(labels.dtype == torch.int32 and labels.numel() == n and table is not None and table.dtype == torch.float32
+             and table.is_contiguous() and table.numel() == 3 * 2 * F_, "fourier_pe: labels/table")
+    hip.check(hip.lib().marship_fourier_pe(ptr(coords), ptr(G), F_, ptr(labels), ptr(table), ptr(out), 2 * F_, n, stream()),
+              "marship_fourier_pe")
+
+
+def add_cast(a: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor):
+    """out = a + b (b broadcast over leading rows by repetition), f32 -> out.dtype; a, out [rows, D] contiguous."""
+    _dev(a, b, out)
+    _req(a.dtype == torch.float32 and a.is_contiguous() and out.is_contiguous() and out.numel() == a.numel(), "add_cast: a/out")
+    D = a.shape[-1]
+    rows = a.numel() // D
+    b_rows = 1
+    if b is not None:
+        _req(b.dtype == torch.float32 and b.is_contiguous() and b.shape[-1] == D and rows % (b.numel() // D) == 0, "add_cast: b")
+        b_rows = b.numel() // D
+    hip.check(hip.lib().marship_add_cast(ptr(a), ptr(b), b_rows, ptr(out), rows, D, dt(out), stream()), "marship_add_cast")
+
+
+def act_cast(x: torch.Tensor, out: torch.Tensor, act: int):
+    _dev(x, out)
+    _req(x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous() and out.numel() == x.numel(), "act_cast")
+    hip.check(hip.lib().marship_act_cast(ptr(x), ptr(out), x.numel(), act, dt(out), stream()), "marship_act_cast")
+
+
+def mask_stats(masks: torch.Tensor, thr: float, off: float, out: torch.Tensor):
+    _dev(masks, out)
+    _req(masks.dim() == 3 and masks.is_contiguous() and masks.dtype == torch.float32, "mask_stats: masks must be f32 [n,H,W]")
+    _req(out.dtype == torch.int32 and out.is_contiguous() and out.numel() >= 6 * masks.shape[0], "mask_stats: out")
+    n, H, W = masks.shape
+    hip.check(hip.lib().marship_mask_stats(ptr(masks), n, H, W, float(thr), float(off), ptr(out), stream()), "marship_mask_stats")
+
+
+def threshold_masks(src: torch.Tensor, thr: float, dst: torch.Tensor):
+    _dev(src, dst)
+    _req(src.dtype == torch.float32 and dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() >= src.numel(),
+         "threshold_masks")
+    hip.check(hip.lib().marship_threshold_masks(ptr(src), float(thr), ptr(dst), src.numel(), stream()), "marship_threshold_masks")
+
+
+def box_nms_host(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Greedy NMS on host tensors; returns the kept indices (int64) by decreasing score."""
+    b = boxes.detach().cpu().float().contiguous()
+    s = scores.detach().cpu().float().contiguous()
+    n = b.shape[0]
+    keep = torch.zeros(max(n, 1), dtype=torch.int32)
+    cnt = ctypes.c_int32(0)
+    hip.check(hip.lib().marshost_box_nms(_vp(b.data_ptr()), _vp(s.data_ptr()), n, float(iou_threshold), _vp(keep.data_ptr()), ctypes.byref(cnt)),
+              "marshost_box_nms")
+    return keep[: cnt.value].long()

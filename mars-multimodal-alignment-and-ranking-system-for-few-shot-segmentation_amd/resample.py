@@ -79,12 +79,20 @@ def _pil_bicubic(x: float) -> float:
     return 0.0
 
 
+def _pil_bilinear(x: float) -> float:
+    if x < 0.0:
+        x = -x
+    return 1.0 - x if x < 1.0 else 0.0
+
+
 @lru_cache(maxsize=None)
-def pil_table_u8(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Pillow BICUBIC 8-bit coefficients: (xmin int32, xsize int32, kk int32 [out, ksize])."""
+def pil_table_u8(in_size: int, out_size: int, filt: str = "bicubic") -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Pillow 8-bit coefficients, BICUBIC (support 2) or BILINEAR (support 1):
+    (xmin int32, xsize int32, kk int32 [out, ksize])."""
+    _pil_filter, base_support = {"bicubic": (_pil_bicubic, 2.0), "bilinear": (_pil_bilinear, 1.0)}[filt]
     scale = float(in_size) / out_size
     filterscale = max(scale, 1.0)
-    support = 2.0 * filterscale
+    support = base_support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     xmin = np.zeros(out_size, np.int32)
     xsize = np.zeros(out_size, np.int32)
@@ -95,7 +103,7 @@ def pil_table_u8(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, n
         lo = max(int(center - support + 0.5), 0)
         hi = min(int(center + support + 0.5), in_size)
         n = hi - lo
-        k = [_pil_bicubic((x + lo - center + 0.5) * ss) for x in range(n)]
+        k = [_pil_filter((x + lo - center + 0.5) * ss) for x in range(n)]
         ww = 0.0
         for v in k:
             ww += v
@@ -105,3 +113,49 @@ def pil_table_u8(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, n
             kk[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
         xmin[xx], xsize[xx] = lo, n
     return xmin, xsize, kk
+
+
+@lru_cache(maxsize=None)
+def torch_bilinear_matrix(in_size: int, out_size: int) -> np.ndarray:
+    """Dense [out, in] float64 matrix of F.interpolate(mode='bilinear', align_corners=False) along one
+    axis (ATen area_pixel_compute_source_index: float32 source coordinate, clamped at 0)."""
+    scale = f32(f32(in_size) / f32(out_size))
+    M = np.zeros((out_size, in_size), np.float64)
+    for o in range(out_size):
+        src = f32(f32(scale * f32(o + 0.5)) - f32(0.5))
+        if src < 0:
+            src = f32(0.0)
+        i0 = int(src)
+        i1 = min(i0 + 1, in_size - 1)
+        l1 = f32(src - f32(i0))
+        l0 = f32(f32(1.0) - l1)
+        M[o, i0] += float(l0)
+        M[o, i1] += float(l1)
+    return M
+
+
+def matrix_to_table(M: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Banded [out, in] matrix -> (xmin, xsize, weights [out, kmax]) of the resample kernels."""
+    out_size = M.shape[0]
+    nz = [np.nonzero(M[o])[0] for o in range(out_size)]
+    xmin = np.array([int(v[0]) if len(v) else 0 for v in nz], np.int32)
+    xsize = np.array([int(v[-1]) - int(v[0]) + 1 if len(v) else 0 for v in nz], np.int32)
+    kmax = max(1, int(xsize.max()))
+    wts = np.zeros((out_size, kmax), np.float32)
+    for o in range(out_size):
+        wts[o, : xsize[o]] = M[o, xmin[o]: xmin[o] + xsize[o]]
+    return xmin, xsize, wts
+
+
+@lru_cache(maxsize=None)
+def torch_bilinear_table(in_size: int, out_size: int):
+    return matrix_to_table(torch_bilinear_matrix(in_size, out_size))
+
+
+@lru_cache(maxsize=None)
+def sam_postprocess_table(low_size: int, img_size: int, input_len: int, orig_len: int):
+    """One axis of Sam.postprocess_masks (/root/reference/segment_anything/modeling/sam.py:134-162):
+    bilinear low_size -> img_size, keep the first input_len samples, bilinear -> orig_len, composed
+    into a single banded table."""
+    up = torch_bilinear_matrix(low_size, img_size)[:input_len]
+    return matrix_to_table(torch_bilinear_matrix(input_len, orig_len) @ up)

@@ -1,0 +1,137 @@
+"""Automatic mask generator on the HIP kernels.
+
+Interface of /root/reference/segment_anything/automatic_mask_generator.py:38-243 (dense point grid,
+one crop layer): ``generate(image) -> list of records`` with the reference's keys, plus
+``generate_proposals`` which hands the ranking path a fixed-size float {0,1} tensor.
+
+Per batch of points the decoder output is resampled to the image size once; one kernel then gives
+the two stability counts and the box of every mask, so the filters (predicted IoU, stability) run
+on a few integers per mask on the host, and only the surviving masks are kept (as {0,1} floats on
+the GPU).  Box NMS runs on the host.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from .modeling import Sam
+from .predictor import SamPredictor
+
+
+def build_point_grid(n_per_side: int) -> np.ndarray:
+    """utils/amg.py:179-187."""
+    offset = 1 / (2 * n_per_side)
+    side = np.linspace(offset, 1 - offset, n_per_side)
+    return np.stack([np.tile(side[None, :], (n_per_side, 1)), np.tile(side[:, None], (1, n_per_side))], axis=-1).reshape(-1, 2)
+
+
+class SamAutomaticMaskGenerator:
+    def __init__(self, model: Sam, points_per_side: Optional[int] = 32, points_per_batch: int = 64, pred_iou_thresh: float = 0.88,
+                 stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0, box_nms_thresh: float = 0.7,
+                 crop_n_layers: int = 0, point_grids: Optional[List[np.ndarray]] = None, min_mask_region_area: int = 0,
+                 output_mode: str = "binary_mask", multimask_output: bool = True, **unused):
+        assert (points_per_side is None) != (point_grids is None), "Exactly one of points_per_side or point_grid must be provided."
+        if crop_n_layers != 0 or min_mask_region_area != 0 or output_mode != "binary_mask":
+            raise NotImplementedError("one crop layer, binary masks, no small-region post-processing")
+        self.point_grids = [build_point_grid(points_per_side)] if points_per_side is not None else point_grids
+        self.predictor = SamPredictor(model)
+        self.points_per_batch = points_per_batch
+        self.pred_iou_thresh = pred_iou_thresh
+        self.stability_score_thresh = stability_score_thresh
+        self.stability_score_offset = stability_score_offset
+        self.box_nms_thresh = box_nms_thresh
+        self.multimask_output = multimask_output
+        self.stored_features: Dict[Any, Any] = {}
+
+    def reset_stored_features(self):
+        self.stored_features = {}
+
+    # ------------------------------------------------------------------ lines 385-453
+    def _process_batch(self, points: np.ndarray, im_size, keep_lists: dict):
+        pr, dev = self.predictor, self.predictor.device
+        oh, ow = im_size
+        tp = torch.as_tensor(pr.transform.apply_coords(points, im_size), dtype=torch.float32, device=dev)
+        labels = torch.ones(tp.shape[0], 1, dtype=torch.int32, device=dev)
+        masks, iou, low = pr.predict_torch(tp[:, None, :], labels, multimask_output=self.multimask_output, return_logits=True)
+        nm = masks.shape[1]
+        masks, iou, low = masks.flatten(0, 1), iou.flatten(0, 1), low.flatten(0, 1)
+        stats = torch.empty(masks.shape[0], 6, dtype=torch.int32, device=dev)
+        ops.mask_stats(masks, pr.model.mask_threshold, self.stability_score_offset, stats)
+        st, iou_h = stats.cpu(), iou.cpu()
+        stab = st[:, 0].float() / st[:, 1].float()                    # intersections / unions (amg.py:173)
+        keep = torch.ones(masks.shape[0], dtype=torch.bool)
+        if self.pred_iou_thresh > 0.0:
+            keep &= iou_h > self.pred_iou_thresh
+        if self.stability_score_thresh > 0.0:
+            keep &= stab >= self.stability_score_thresh
+        idx = torch.nonzero(keep).flatten()
+        if idx.numel() == 0:
+            return
+        sel = idx.to(dev)
+        kept = masks[sel].contiguous()
+        binm = torch.empty_like(kept)
+        ops.threshold_masks(kept, pr.model.mask_threshold, binm)
+        keep_lists["masks"].append(binm)
+        keep_lists["iou"].append(iou_h[idx])
+        keep_lists["stab"].append(stab[idx])
+        keep_lists["boxes"].append(st[idx, 2:6].float())
+        keep_lists["points"].append(torch.as_tensor(points.repeat(nm, axis=0))[idx])
+        keep_lists["low"].append(low[sel])
+
+    # ------------------------------------------------------------------ lines 160-243, 295-383
+    def _run(self, image: np.ndarray) -> dict:
+        oh, ow = image.shape[:2]
+        self.predictor.set_image(image)
+        pts_all = self.point_grids[0] * np.array([[ow, oh]], dtype=np.float64)
+        lists = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
+        for b0 in range(0, len(pts_all), self.points_per_batch):
+            self._process_batch(pts_all[b0:b0 + self.points_per_batch], (oh, ow), lists)
+        self.predictor.reset_image()
+        if not lists["iou"]:
+            return dict(masks=torch.zeros(0, oh, ow, device=self.predictor.device), iou=torch.zeros(0), stab=torch.zeros(0),
+                        boxes=torch.zeros(0, 4), points=torch.zeros(0, 2), low=None, size=(oh, ow))
+        cat = {k: torch.cat(v, dim=0) for k, v in lists.items()}
+        keep = ops.box_nms_host(cat["boxes"], cat["iou"], self.box_nms_thresh)
+        out = {k: (v[keep.to(v.device)] if torch.is_tensor(v) else v) for k, v in cat.items()}
+        out["size"] = (oh, ow)
+        return out
+
+    def generate(self, image: np.ndarray) -> List[Dict[str, Any]]:
+        r = self._run(image)
+        oh, ow = r["size"]
+        recs = []
+        masks_h = r["masks"].cpu().numpy() > 0 if len(r["iou"]) else np.zeros((0, oh, ow), bool)
+        for i in range(len(r["iou"])):
+            x0, y0, x1, y1 = [float(v) for v in r["boxes"][i].tolist()]
+            recs.append({"segmentation": masks_h[i], "area": int(masks_h[i].sum()), "bbox": [x0, y0, x1 - x0, y1 - y0],
+                         "predicted_iou": float(r["iou"][i]), "point_coords": [r["points"][i].tolist()],
+                         "low_res_masks": r["low"][i].cpu().numpy(), "stability_score": float(r["stab"][i]),
+                         "crop_box": [0.0, 0.0, float(ow), float(oh)]})
+        return recs
+
+    def generate_proposals(self, query_image: torch.Tensor, n: int) -> torch.Tensor:
+        """Proposals for the ranking path: [n, H, W] float {0,1} on the GPU from a [1, 3, H, W] float image
+        in [0, 1] - the top n by predicted IoU, padded by repetition (an empty result gives all-ones masks)."""
+        img = query_image[0].mul(255).byte().permute(1, 2, 0).cpu().numpy()
+        r = self._run(img)
+        m = r["masks"]
+        if m.shape[0] == 0:
+            return torch.ones(n, img.shape[0], img.shape[1], dtype=torch.float32, device=self.predictor.device)
+        order = torch.argsort(r["iou"], descending=True, stable=True)[:n]
+        m = m[order.to(m.device)]
+        reps = -(-n // m.shape[0])
+        return m.repeat(reps, 1, 1)[:n].contiguous()
+
+
+class ProposalGenerator:
+    """``mask_generator`` object of MARS (/root/reference/mars/MARS.py:46-51): ``generate(support_images,
+    support_masks, query_image) -> Tensor[N, H, W]``."""
+
+    def __init__(self, amg: SamAutomaticMaskGenerator, n_proposals: int = 64):
+        self.amg, self.n = amg, n_proposals
+
+    def generate(self, support_images, support_masks, query_image) -> torch.Tensor:
+        return self.amg.generate_proposals(query_image, self.n)

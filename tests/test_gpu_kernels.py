@@ -41,7 +41,30 @@ def test_gemm_asymmetric_identity(pkg, cuda):
     assert torch.equal(out, b.t().contiguous())
 
 
-@pytest.mark.parametrize("act", [0, 1, 2])
+def _act(z, act):
+    return F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else (F.relu(z) if act == 3 else z))
+
+
+@pytest.mark.parametrize("variant", [5, 6, 7])
+@pytest.mark.parametrize("act", [1, 3])
+def test_gemm_fast_epilogue_activations(pkg, cuda, variant, act):
+    """erf-GELU and ReLU on the register-direct epilogue of the ring kernels (aligned rows, no residual)."""
+    lib = pkg.hip.lib()
+    M, N, K = 300, 256, 128
+    a, b = _rand((M, K), 31, cuda), _rand((N, K), 32, cuda) * 0.2
+    bias = _rand((N,), 33, cuda)
+    old = lib.marship_set_gemm_variant(variant)
+    try:
+        for dt, tol in ((torch.float32, 2e-4), (torch.bfloat16, 0.05)):
+            out = torch.full((M, N), float("nan"), device=cuda, dtype=dt)
+            pkg.ops.linear(a.to(dt), b.to(dt), out, bias=bias, act=act)
+            ref = _act(a.to(dt).double() @ b.to(dt).double().t() + bias.double(), act)
+            assert float((out.double() - ref).abs().max()) < tol
+    finally:
+        lib.marship_set_gemm_variant(old)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_gemm_epilogue(pkg, cuda, act):
     M, N, K = 77, 200, 128
     a, b = _rand((M, K), 3, cuda), _rand((N, K), 4, cuda) * 0.2
@@ -49,14 +72,12 @@ def test_gemm_epilogue(pkg, cuda, act):
     res = _rand((M, N), 7, cuda)
     out = res.clone()
     pkg.ops.linear(a, b, out, bias=bias, gamma=gamma, residual=out, act=act, alpha=0.5)
-    z = 0.5 * (a @ b.t()) + bias
-    z = F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else z)
+    z = _act(0.5 * (a @ b.t()) + bias, act)
     ref = res + gamma * z
     assert float((out - ref).abs().max()) < 2e-4
     outb = torch.zeros(M, N, device=cuda, dtype=torch.bfloat16)
     pkg.ops.linear(a, b, outb, bias=bias, act=act)
-    z = (a @ b.t()) + bias
-    z = F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else z)
+    z = _act((a @ b.t()) + bias, act)
     assert float((outb.float() - z).abs().max()) < 0.05
 
 
@@ -484,3 +505,56 @@ def test_backward_pieces_against_autograd(pkg, cuda):
     pkg.ops.cam_head(f.detach(), proj, text, 14.285714, lo, df)
     assert float((lo - logits.detach()).abs().max()) < 1e-5
     assert float((df - gf).abs().max()) < 1e-5 * max(1.0, float(gf.abs().max()))
+
+
+# ------------------------------------------------------------------ kernels of the proposal stage
+def test_gather_rows_and_casts(pkg, cuda):
+    ops = pkg.ops
+    src = _rand((50, 96), 41, cuda)
+    idx = torch.tensor([3, -1, 49, 0, 7, 7, -1, 20], dtype=torch.int32, device=cuda)
+    for dt in (torch.float32, torch.bfloat16):
+        s = src.to(dt)
+        dst = torch.full((8, 130), 5.0, device=cuda, dtype=dt)
+        ops.gather_rows(s, idx, dst, src_col=16, dst_col=32, ncols=64)
+        ref = torch.full((8, 130), 5.0, device=cuda, dtype=dt)
+        for r, i in enumerate(idx.tolist()):
+            ref[r, 32:96] = s[i, 16:80] if i >= 0 else 0
+        assert torch.equal(dst, ref)
+    a, b = _rand((12, 40), 42, cuda), _rand((3, 40), 43, cuda)
+    out = torch.empty(12, 40, device=cuda, dtype=torch.bfloat16)
+    ops.add_cast(a, b, out)
+    assert torch.equal(out, (a + b.repeat(4, 1)).to(torch.bfloat16))
+    out32 = torch.empty(12, 40, device=cuda)
+    ops.add_cast(a, None, out32)
+    assert torch.equal(out32, a)
+    for act in (1, 3):
+        o = torch.empty(12, 40, device=cuda)
+        ops.act_cast(a, o, act)
+        assert float((o - _act(a, act)).abs().max()) < 1e-6
+
+
+def test_softmax_bias_rows_and_relpos(pkg, cuda):
+    ops = pkg.ops
+    B, H, gw, hd, hdp = 2, 3, 5, 16, 64
+    T = gw * gw
+    qkv = _rand((B * T, 3 * H * hdp), 44, cuda)
+    Rh, Rw = _rand((gw, gw, hd), 45, cuda), _rand((gw, gw, hd), 46, cuda)
+    rel_h = torch.empty(B * H * T, gw, device=cuda)
+    rel_w = torch.empty(B * H * T, gw, device=cuda)
+    ops.relpos_bias(qkv, B, T, H, hd, hdp, gw, Rh, Rw, rel_h, rel_w)
+    q = qkv[:, : H * hdp].view(B, T, H, hdp)[..., :hd].permute(0, 2, 1, 3).reshape(B * H, gw, gw, hd)
+    ref_h = torch.einsum("bhwc,hkc->bhwk", q, Rh).reshape(-1, gw)
+    ref_w = torch.einsum("bhwc,wkc->bhwk", q, Rw).reshape(-1, gw)
+    assert float((rel_h - ref_h).abs().max()) < 1e-4 and float((rel_w - ref_w).abs().max()) < 1e-4
+    Tp = 64
+    S = _rand((B * H * T, Tp), 47, cuda)
+    for dt in (torch.float32, torch.bfloat16):
+        P = torch.full((B * H * T, Tp), 3.0, device=cuda, dtype=dt)
+        ops.softmax_bias_rows(S.view(B * H, T, Tp), P.view(B * H, T, Tp), B * H * T, T, rel_h, rel_w, gw, gw)
+        bias = (ref_h[:, :, None] + ref_w[:, None, :]).reshape(-1, T)
+        ref = torch.softmax(S[:, :T] + bias, dim=-1)
+        assert float((P[:, :T].float() - ref).abs().max()) < (1e-5 if dt == torch.float32 else 4e-3)
+        assert float(P[:, T:].float().abs().max()) == 0.0           # the K padding of the next product
+    P = torch.empty(B * H * T, Tp, device=cuda)
+    ops.softmax_bias_rows(S.view(B * H, T, Tp), P.view(B * H, T, Tp), B * H * T, T)
+    assert float((P[:, :T] - torch.softmax(S[:, :T], -1)).abs().max()) < 1e-5

@@ -1,0 +1,172 @@
+"""Segment-Anything proposal stage on the HIP kernels against oracle/sam.py and the committed
+vectors made from the reference's segment_anything.modeling modules (tests/golden/make_golden.py).
+
+fp32 tolerances: the GEMMs accumulate in another order than the CPU's, so logits agree to ~1e-4
+and a mask bit may flip only where |logit| is within that distance of the threshold.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+TOL = 2e-4
+
+
+def maxdiff(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max())
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package(require_native=True)
+
+
+@pytest.fixture(scope="module", params=["tiny", "tiny80"])
+def setup(request, pkg):
+    from oracle import sam as osam
+    arch = request.param
+    cfg = pkg.synth.SAM_ARCHS[arch]
+    sd = pkg.synth.sam_state_dict(cfg, seed=5)
+    sam = pkg.segment_anything.sam_model_registry[arch](state_dict=sd, device="cuda", dtype=torch.float32)
+    return arch, cfg, sd, sam, osam
+
+
+def test_encoder_matches_reference_vectors(setup, pkg):
+    arch, cfg, sd, sam, osam = setup
+    pred = pkg.segment_anything.SamPredictor(sam)
+    pred.set_image(GOLD[f"sam_{arch}_image"])
+    assert pred.input_size == osam.preprocess_shape(*GOLD[f"sam_{arch}_image"].shape[:2], cfg.img_size)
+    assert maxdiff(pred.features, GOLD[f"sam_{arch}_features"]) < TOL
+    # module-style call on an already normalised, padded batch
+    state = osam.set_image(sd, cfg.oracle_kw(), GOLD[f"sam_{arch}_image"])
+    img = torch.as_tensor(osam.apply_image(GOLD[f"sam_{arch}_image"], cfg.img_size)).permute(2, 0, 1)[None].float()
+    out = sam.image_encoder(osam.preprocess(img, cfg.img_size).cuda())
+    assert maxdiff(out, state["features"]) < TOL
+
+
+def test_prompt_encoder(setup):
+    arch, cfg, sd, sam, osam = setup
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(5, 2, 2, generator=g) * cfg.img_size
+    lab = torch.tensor([[1, 0], [1, 1], [0, -1], [1, -1], [0, 0]])
+    ref = osam.embed_points(sd, pts, lab.float(), (cfg.img_size, cfg.img_size))
+    sparse, dense = sam.prompt_encoder(points=(pts.cuda(), lab.cuda()), boxes=None, masks=None)
+    assert maxdiff(sparse, ref) < 2e-5
+    G = cfg.img_size // cfg.patch_size
+    assert maxdiff(sam.prompt_encoder.get_dense_pe(), osam.dense_pe(sd, (G, G))) < 2e-5
+    assert dense.shape == (5, cfg.out_chans, G, G)
+    assert maxdiff(dense[2, :, 1, 1], sd["prompt_encoder.no_mask_embed.weight"][0]) == 0.0
+
+
+def test_decoder_and_postprocess_match_reference_vectors(setup, pkg):
+    arch, cfg, sd, sam, osam = setup
+    pred = pkg.segment_anything.SamPredictor(sam)
+    # start from the reference's embedding so the decoder is checked on its own
+    pred.set_image(GOLD[f"sam_{arch}_image"], stored_features=torch.as_tensor(GOLD[f"sam_{arch}_features"]))
+    pts = torch.as_tensor(GOLD[f"sam_{arch}_points"]).float()
+    masks, iou, low = pred.predict_torch(pts[:, None, :].cuda(), torch.ones(len(pts), 1, dtype=torch.int32).cuda(), return_logits=True)
+    assert maxdiff(low, GOLD[f"sam_{arch}_low_res"]) < TOL
+    assert maxdiff(iou, GOLD[f"sam_{arch}_iou"]) < TOL
+    assert maxdiff(masks, GOLD[f"sam_{arch}_masks"]) < TOL
+    # module-style decoder call, single-mask output
+    G = cfg.img_size // cfg.patch_size
+    feats = torch.as_tensor(GOLD[f"sam_{arch}_features"]).cuda()
+    sparse, dense = sam.prompt_encoder(points=(pts[:, None, :].cuda(), torch.ones(len(pts), 1).cuda()), boxes=None, masks=None)
+    low1, iou1 = sam.mask_decoder(image_embeddings=feats, image_pe=sam.prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=sparse,
+                                  dense_prompt_embeddings=dense, multimask_output=False)
+    state = dict(features=torch.as_tensor(GOLD[f"sam_{arch}_features"]))
+    ref_sparse = osam.embed_points(sd, pts[:, None, :], torch.ones(len(pts), 1), (cfg.img_size, cfg.img_size))
+    ref_dense = sd["prompt_encoder.no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(len(pts), -1, G, G)
+    rlow, riou = osam.mask_decoder(sd, state["features"], osam.dense_pe(sd, (G, G)), ref_sparse, ref_dense, cfg.oracle_kw(), False)
+    assert low1.shape == rlow.shape and maxdiff(low1, rlow) < TOL and maxdiff(iou1, riou) < TOL
+    # end to end (own encoder): binary masks differ only where the logit is at the threshold
+    pred.set_image(GOLD[f"sam_{arch}_image"])
+    bm, _, _ = pred.predict_torch(pts[:, None, :].cuda(), torch.ones(len(pts), 1, dtype=torch.int32).cuda())
+    ref = torch.as_tensor(GOLD[f"sam_{arch}_masks"])
+    flips = (bm.cpu() != (ref > 0))
+    assert bool((ref[flips].abs() < 5 * TOL).all())
+
+
+def test_preprocess_and_transforms(setup, pkg):
+    arch, cfg, sd, sam, osam = setup
+    img = GOLD[f"sam_{arch}_image"]
+    t = torch.as_tensor(osam.apply_image(img, cfg.img_size)).permute(2, 0, 1)[None].float()
+    assert maxdiff(sam.preprocess(t.cuda()), osam.preprocess(t, cfg.img_size)) < 1e-6
+    tr = pkg.segment_anything.predictor.ResizeLongestSide(cfg.img_size)
+    c = np.array([[3.0, 5.0], [60.5, 20.25]])
+    assert np.array_equal(tr.apply_coords(c, img.shape[:2]), osam.apply_coords(c, img.shape[:2], cfg.img_size))
+    g = torch.Generator().manual_seed(4)
+    low = torch.randn(3, 2, 4 * (cfg.img_size // cfg.patch_size), 4 * (cfg.img_size // cfg.patch_size), generator=g)
+    insz = osam.preprocess_shape(*img.shape[:2], cfg.img_size)
+    for orig in (img.shape[:2], (57, 41)):
+        got = sam.postprocess_masks(low.cuda(), insz, orig)
+        assert maxdiff(got, osam.postprocess_masks(low, cfg.img_size, insz, orig)) < 2e-5
+
+
+def test_mask_statistics_and_nms(pkg):
+    from oracle import sam as osam
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(8)
+    m = torch.randn(7, 33, 50, generator=g) * 2
+    m[3] = -5.0                                                       # empty mask
+    m[4, 10:12, 7:30] = 9.0
+    stats = torch.empty(7, 6, dtype=torch.int32, device="cuda")
+    ops.mask_stats(m.cuda(), 0.0, 1.0, stats)
+    st = stats.cpu()
+    assert torch.equal(st[:, 0], (m > 1.0).sum((1, 2)).int()) and torch.equal(st[:, 1], (m > -1.0).sum((1, 2)).int())
+    assert torch.equal(st[:, 2:6].long(), osam.mask_to_box(m > 0.0))
+    b = torch.empty_like(m, device="cuda")
+    ops.threshold_masks(m.cuda(), 0.0, b)
+    assert torch.equal(b.cpu() > 0, m > 0)
+    boxes = torch.rand(200, 4, generator=g) * 50
+    boxes[:, 2:] += boxes[:, :2]
+    scores = torch.rand(200, generator=g)
+    scores[10] = scores[20]                                          # a tie: stable order
+    for thr in (0.3, 0.7):
+        assert torch.equal(ops.box_nms_host(boxes, scores, thr), osam.box_nms(boxes, scores, thr))
+
+
+def test_generator_matches_oracle(pkg):
+    from oracle import sam as osam
+    sa = pkg.segment_anything
+    cfg = pkg.synth.SAM_ARCHS["tiny"]
+    sd = pkg.synth.sam_state_dict(cfg, seed=5)
+    sam = sa.sam_model_registry["tiny"](state_dict=sd, device="cuda")
+    img = GOLD["sam_tiny_image"]
+    kw = dict(points_per_side=4, points_per_batch=5, pred_iou_thresh=-10.0, stability_score_thresh=0.0, box_nms_thresh=0.7)
+    recs = sa.SamAutomaticMaskGenerator(sam, **kw).generate(img)
+    ref = osam.generate(sd, cfg.oracle_kw(), img, **kw)
+    assert len(recs) == len(ref) >= 1
+    for a, b in zip(recs, ref):
+        assert a["point_coords"] == b["point_coords"] and abs(a["predicted_iou"] - b["predicted_iou"]) < TOL
+        assert float((a["segmentation"] != b["segmentation"]).mean()) < 2e-3
+        assert np.abs(np.array(a["bbox"]) - np.array(b["bbox"])).max() <= 1 and abs(a["area"] - b["area"]) <= 4
+        assert maxdiff(a["low_res_masks"], b["low_res_masks"]) < TOL
+        assert abs(a["stability_score"] - b["stability_score"]) < 5e-3 and a["crop_box"] == [0.0, 0.0, float(img.shape[1]), float(img.shape[0])]
+    # filters: an IoU threshold nothing reaches gives no record
+    assert sa.SamAutomaticMaskGenerator(sam, points_per_side=4, points_per_batch=16, pred_iou_thresh=10.0).generate(img) == []
+    # stability threshold at the oracle's median keeps the same points
+    kw2 = dict(kw, stability_score_thresh=float(np.median([r["stability_score"] for r in ref])) + 1e-3)
+    a2, b2 = sa.SamAutomaticMaskGenerator(sam, **kw2).generate(img), osam.generate(sd, cfg.oracle_kw(), img, **kw2)
+    assert [r["point_coords"] for r in a2] == [r["point_coords"] for r in b2]
+
+
+def test_proposals_feed_the_ranking_pipeline(pkg):
+    sa = pkg.segment_anything
+    sam = sa.sam_model_registry["tiny"](state_dict=pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["tiny"], seed=5), device="cuda")
+    amg = sa.SamAutomaticMaskGenerator(sam, points_per_side=4, points_per_batch=16, pred_iou_thresh=-10.0, stability_score_thresh=0.0)
+    gen = sa.ProposalGenerator(amg, n_proposals=6)
+    q = torch.as_tensor(GOLD["sam_tiny_image"]).permute(2, 0, 1)[None].float().div(255).cuda()
+    props = gen.generate(None, None, q)
+    assert props.shape == (6,) + tuple(q.shape[-2:]) and props.dtype == torch.float32 and props.is_cuda
+    assert set(props.unique().tolist()) <= {0.0, 1.0}

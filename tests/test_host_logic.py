@@ -147,3 +147,48 @@ def test_oracle_compute_iou():
     miou, fb = opipe.compute_iou(inter, union, [0, 4, 8])
     assert abs(miou - (0.5 + 0.75 + 0.0) / 3 * 100) < 1e-4
     assert abs(fb - ((900 + 960) / (950 + 970) + 80 / 140) / 2 * 100) < 1e-4
+
+
+def test_pillow_bilinear_table_is_bit_exact():
+    """The 8-bit BILINEAR coefficients reproduce PIL.Image.resize exactly (SAM's ResizeLongestSide)."""
+    from PIL import Image
+    resample = importlib.import_module(load_package(require_native=False).__name__ + ".resample")
+    rng = np.random.default_rng(2)
+    for (h, w), (nh, nw) in (((37, 53), (90, 128)), ((100, 126), (102, 128)), ((64, 40), (33, 21))):
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        want = np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+
+        def axis_pass(a, n_out, axis):
+            xmin, xsize, kk = resample.pil_table_u8(a.shape[axis], n_out, "bilinear")
+            a = np.moveaxis(a.astype(np.int64), axis, -1)
+            out = np.zeros(a.shape[:-1] + (n_out,), np.int64)
+            for o in range(n_out):
+                out[..., o] = (a[..., xmin[o]: xmin[o] + xsize[o]] * kk[o, : xsize[o]]).sum(-1)
+            out = np.clip((out + (1 << 21)) >> 22, 0, 255)
+            return np.moveaxis(out, -1, axis).astype(np.uint8)
+        got = axis_pass(axis_pass(img, nw, 1), nh, 0)
+        assert np.array_equal(got, want)
+
+
+def test_bilinear_and_composite_tables_match_interpolate():
+    resample = importlib.import_module(load_package(require_native=False).__name__ + ".resample")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 2, 32, 32, generator=g)
+    M = resample.torch_bilinear_matrix(32, 75)
+    want = F.interpolate(x, (75, 75), mode="bilinear", align_corners=False)
+    got = torch.einsum("oi,bcij,pj->bcop", torch.from_numpy(M).float(), x, torch.from_numpy(M).float())
+    assert float((got - want).abs().max()) < 1e-5
+    # Sam.postprocess_masks on one axis pair: 32 -> 128, crop to (102, 128), -> (100, 126)
+    up = F.interpolate(x, (128, 128), mode="bilinear", align_corners=False)[..., :102, :128]
+    want = F.interpolate(up, (100, 126), mode="bilinear", align_corners=False)
+    th = resample.sam_postprocess_table(32, 128, 102, 100)
+    tw = resample.sam_postprocess_table(32, 128, 128, 126)
+
+    def dense(t, n_in):
+        xmin, xsize, w = t
+        D = np.zeros((len(xmin), n_in), np.float32)
+        for o in range(len(xmin)):
+            D[o, xmin[o]: xmin[o] + xsize[o]] = w[o, : xsize[o]]
+        return torch.from_numpy(D)
+    got = torch.einsum("oi,bcij,pj->bcop", dense(th, 32), x, dense(tw, 32))
+    assert float((got - want).abs().max()) < 1e-5

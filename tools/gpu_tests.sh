@@ -21,6 +21,7 @@ for g in "$@"; do
         models) run models tests/test_gpu_models.py ;;
         pipeline) run pipeline tests/test_gpu_pipeline.py ;;
         shells) run shells tests/test_gpu_matcher_clip_pipeline.py ;;
+        sam) run sam tests/test_gpu_sam.py ;;
     esac
 done
 exit 0
