@@ -170,3 +170,32 @@ def test_proposals_feed_the_ranking_pipeline(pkg):
     props = gen.generate(None, None, q)
     assert props.shape == (6,) + tuple(q.shape[-2:]) and props.dtype == torch.float32 and props.is_cuda
     assert set(props.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_episode_with_generated_proposals(pkg):
+    """MARS(mask_generator=...) end to end: proposals come from the generator, the ranking path then
+    agrees with the CPU oracle of the ranking path fed the same proposals."""
+    import importlib
+    from oracle import pipeline as opipe
+    from tests.helpers import tiny_config
+    sa = pkg.segment_anything
+    cfg = tiny_config(pkg)
+    ep = pkg.synth.make_episode(11, size=cfg["size"], nshot=cfg["nshot"], nprop=cfg["nprop"])
+    sam = sa.sam_model_registry["tiny"](state_dict=pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["tiny"], seed=5), device="cuda")
+    # no suppression: the ranking needs distinct proposals (min-max scaling of exactly tied scores is 0/0)
+    amg = sa.SamAutomaticMaskGenerator(sam, points_per_side=4, points_per_batch=16, pred_iou_thresh=-10.0, stability_score_thresh=0.0,
+                                       box_nms_thresh=1.0)
+    gen = sa.ProposalGenerator(amg, n_proposals=cfg["nprop"])
+    MARS = importlib.import_module(pkg.__name__ + ".mars.MARS")
+    mars = MARS.build_MARS_fss(cfg["args"], state_dicts=cfg["sds"])
+    mars.mask_generator = gen
+    dev = "cuda"
+    pred = mars.predict(ep["support_imgs"].to(dev), ep["support_masks"].to(dev), ep["query_img"].to(dev))
+    props = gen.generate(None, None, ep["query_img"].to(dev))
+    assert len({int(v) for v in props.sum((1, 2)).tolist()}) == cfg["nprop"]
+    ep2 = dict(ep, mask_proposals=props.cpu())
+    ref = opipe.mars_predict(cfg["oracle_models"], ep2, cfg["tokens"])
+    got = mars.filtering_merging_component.scores()
+    assert maxdiff(got["score"], ref["scores"]["score"]) < 1e-4
+    assert got["order"].tolist() == ref["scores"]["order"].tolist()
+    assert int((pred.cpu() != ref["mask"]).sum()) == 0
