@@ -41,10 +41,21 @@ __device__ unsigned long long* mars_stamp_buf;
 #define MARS_STAMP_ID()
 #endif
 
+// experiment switches of the diagnostic build: drop the loop's DMAs / fragment reads / MFMAs
+#ifndef MARS_EXP_DMA
+#define MARS_EXP_DMA 1
+#endif
+#ifndef MARS_EXP_READ
+#define MARS_EXP_READ 1
+#endif
+#ifndef MARS_EXP_MMA
+#define MARS_EXP_MMA 1
+#endif
+
 namespace {
 
 constexpr int STEP_B = 64;                               // bytes of K per row and step
-constexpr int RING = 3, FN = 4;
+constexpr int RING = 3;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -84,14 +95,15 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
     }
 }
 
-// NWR x NWC waves, each FM x 4 fragments (16 FM x 64 outputs); WPE = waves per SIMD the register
+// NWR x NWC waves, each FM x FN fragments (16 FM x 16 FN outputs); WPE = waves per SIMD the register
 // budget must allow (workgroups per CU x waves per workgroup / 4).
-template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int WPE>
+template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE>
 __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g, int group_m) {
-    constexpr int BM = 16 * FM * NWR, BN = 64 * NWC, NWAVES = NWR * NWC;
+    constexpr int BM = 16 * FM * NWR, WN = 16 * FN, BN = WN * NWC, NWAVES = NWR * NWC;
     constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
     static_assert((BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0, "DMA pieces must divide among the waves");
     static_assert(FM == 2 || FM == 4 || FM == 8, "wave tile is 32, 64 or 128 rows");
+    static_assert(FN == 4 || FN == 8, "wave tile is 64 or 128 columns");
     constexpr int A_PIECES = BM / 16 / NWAVES, B_PIECES = BN / 16 / NWAVES;   // 1-KiB DMAs per wave and step
     constexpr int PIECES = A_PIECES + B_PIECES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[RING * STAGE];
@@ -138,13 +150,27 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
             pb[i] = Bb + gb * ldb_b + (chunk << 4);
         }
     }
-    auto issue = [&](int s, int slot) {
+    // piece p of this wave's share of step s (A pieces first), into ring slot `slot`
+    auto issue_piece = [&](int s, int slot, auto p_tag) {
+        constexpr int p = decltype(p_tag)::value;
         unsigned char* sa = lds + slot * STAGE;
         const int64_t ko = (int64_t)s * STEP_B;
-#pragma unroll
-        for (int i = 0; i < A_PIECES; ++i) glds16(pa[i] + ko, sa + (i * NWAVES + wave) * 1024);
-#pragma unroll
-        for (int i = 0; i < B_PIECES; ++i) glds16(pb[i] + ko, sa + A_BYTES + (i * NWAVES + wave) * 1024);
+        if constexpr (p < A_PIECES) glds16(pa[p] + ko, sa + (p * NWAVES + wave) * 1024);
+        else glds16(pb[p - A_PIECES] + ko, sa + A_BYTES + ((p - A_PIECES) * NWAVES + wave) * 1024);
+    };
+    auto issue = [&](int s, int slot) {
+        [&]<int... P>(std::integer_sequence<int, P...>) { (issue_piece(s, slot, std::integral_constant<int, P>{}), ...); }
+        (std::make_integer_sequence<int, PIECES>{});
+    };
+    // the pieces of a step that are issued in front of fragment row m's MFMAs: a DMA issue blocks the wave
+    // while the CU's load path is busy (about 36 cycles per piece already queued), so the pieces are spread
+    // over the step instead of queued behind one another while the matrix pipe waits
+    auto issue_row = [&](int s, int slot, auto m_tag) {
+        constexpr int m = decltype(m_tag)::value;
+        [&]<int... P>(std::integer_sequence<int, P...>) {
+            ((P * FM / PIECES == m ? issue_piece(s, slot, std::integral_constant<int, P>{}) : (void)0), ...);
+        }
+        (std::make_integer_sequence<int, PIECES>{});
     };
 
     f32x4 acc[FM][FN];
@@ -163,8 +189,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     auto frag_off = [&](int row) { return row * STEP_B + ((kq ^ gsw((row >> 2) & 3)) << 4); };
     const unsigned a_off = wr * (16 * FM) * STEP_B + frag_off(r16);
     const int brow = PERM ? 8 * (r16 >> 2) + (r16 & 3) : r16;          // fragment 0; fragment 1 is 4 / 16 rows on
-    const unsigned b_off0 = A_BYTES + wc * 64 * STEP_B + frag_off(brow);
-    const unsigned b_off1 = A_BYTES + wc * 64 * STEP_B + frag_off(brow + (PERM ? 4 : 16));
+    const unsigned b_off0 = A_BYTES + wc * WN * STEP_B + frag_off(brow);
+    const unsigned b_off1 = A_BYTES + wc * WN * STEP_B + frag_off(brow + (PERM ? 4 : 16));
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)lds;
 
     // ---- main loop: the fragments of step s+1 are read while the MFMAs of step s run ----
@@ -173,6 +199,9 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         const unsigned sbase = lds_base + (unsigned)(slot_ * STAGE);
         const unsigned aa = sbase + a_off, ba0 = sbase + b_off0, ba1 = sbase + b_off1;
         lds_read128<0>(FB[0], ba0); lds_read128<0>(FB[1], ba1); lds_read128<2048>(FB[2], ba0); lds_read128<2048>(FB[3], ba1);
+        if constexpr (FN == 8) {
+            lds_read128<4096>(FB[4], ba0); lds_read128<4096>(FB[5], ba1); lds_read128<6144>(FB[6], ba0); lds_read128<6144>(FB[7], ba1);
+        }
         lds_read128<0>(FA[0], aa); lds_read128<1024>(FA[1], aa);
         if constexpr (FM >= 4) { lds_read128<2048>(FA[2], aa); lds_read128<3072>(FA[3], aa); }
         if constexpr (FM == 8) {
@@ -180,27 +209,48 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         }
     };
 #define MARS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    // fragment read j of a step (B fragments first) into the idle register set
+    auto read_one = [&](uint4 (&FA)[FM], uint4 (&FB)[FN], int slot_, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        const unsigned sbase = lds_base + (unsigned)(slot_ * STAGE);
+        if constexpr (j < FN) lds_read128<(j >> 1) * 2048>(FB[j], sbase + ((j & 1) ? b_off1 : b_off0));
+        else lds_read128<(j - FN) * 1024>(FA[j - FN], sbase + a_off);
+    };
     // One step.  At its top the DMAs of steps s+1 and s+2 are this wave's outstanding ones; step
     // s+1 must have landed (for every wave: barrier) before its fragments are fetched, and the same
     // barrier says that everybody has the fragments of step s in registers, so its slot can take
-    // step s+3.  Fragment reads are inline asm on purpose: hipcc treats an in-flight LDS-DMA as a
-    // pending LDS write and would put s_waitcnt vmcnt(0) in front of any ds_read it can see,
-    // draining the ring.  `slot` is the ring slot of step s.
-#define MARS_PHASE(CA, CB, NA, NB, s_)                                                               \
+    // step s+3.  The step's DMAs and fragment reads are dealt out between the rows of MFMAs: issued
+    // in a bunch behind the barrier, eight waves' worth of them queue up in the load path and in the
+    // LDS, and every wave sits in its issue slot while the matrix pipe idles.  Fragment reads are
+    // inline asm on purpose: hipcc treats an in-flight LDS-DMA as a pending LDS write and would put
+    // s_waitcnt vmcnt(0) in front of any ds_read it can see, draining the ring.  `slot` is the ring
+    // slot of step s.  MAIN steps (s + 3 < ns) have no conditions in them; the reads of the last
+    // step fetch a stale slot into registers nobody uses.
+#define MARS_PHASE(CA, CB, NA, NB, s_, MAIN)                                                         \
     {                                                                                                 \
         const int nslot = slot + 1 == RING ? 0 : slot + 1;                                            \
-        if ((s_) + 1 < ns) {                                                                          \
-            if ((s_) + 2 < ns) MARS_WAIT_VM(PIECES);                                                  \
+        if (MAIN || (s_) + 1 < ns) {                                                                  \
+            if (MAIN || (s_) + 2 < ns) MARS_WAIT_VM(PIECES);                                          \
             else MARS_WAIT_VM(0);                                                                     \
             __builtin_amdgcn_s_barrier();                                                             \
             asm volatile("" ::: "memory");                                                            \
-            if ((s_) + 3 < ns) issue((s_) + 3, slot);                                                 \
-            read_frags(NA, NB, nslot);                                                                \
         }                                                                                             \
+        const bool more = MARS_EXP_DMA && (MAIN || (s_) + 3 < ns);                                    \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        _Pragma("unroll") for (int m = 0; m < FM; ++m)                                                \
-            _Pragma("unroll") for (int n = 0; n < FN; ++n) mma_step<TIN>(acc[m][n], CB[n], CA[m]);     \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
+        auto row = [&](auto mi_tag) {                                                                 \
+            constexpr int M_ = decltype(mi_tag)::value;                                               \
+            if (more) issue_row((s_) + 3, slot, mi_tag);                                              \
+            if (MARS_EXP_READ) {                                                                      \
+                [&]<int... J>(std::integer_sequence<int, J...>) {                                     \
+                    ((J * FM / (FM + FN) == M_ ? read_one(NA, NB, nslot, std::integral_constant<int, J>{}) : (void)0), ...); \
+                }                                                                                     \
+                (std::make_integer_sequence<int, FM + FN>{});                                         \
+            }                                                                                         \
+            if (MARS_EXP_MMA) _Pragma("unroll") for (int n = 0; n < FN; ++n) mma_step<TIN>(acc[M_][n], CB[n], CA[M_]); \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        };                                                                                            \
+        [&]<int... Mi>(std::integer_sequence<int, Mi...>) { (row(std::integral_constant<int, Mi>{}), ...); } \
+        (std::make_integer_sequence<int, FM>{});                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         slot = nslot;                                                                                 \
@@ -220,8 +270,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     MARS_STAMP(1)
     int slot = 0;
     for (int s = 0; s < ns; s += 2) {
-        MARS_PHASE(faA, fbA, faB, fbB, s)
-        if (s + 1 < ns) MARS_PHASE(faB, fbB, faA, fbA, s + 1)
+        MARS_PHASE(faA, fbA, faB, fbB, s, false)
+        if (s + 1 < ns) MARS_PHASE(faB, fbB, faA, fbA, s + 1, false)
     }
 #undef MARS_PHASE
 #undef MARS_WAIT_VM
@@ -237,24 +287,25 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     // N-edge tiles, unaligned rows, an activation together with a residual - goes through LDS
     // in slabs of 32 rows and a per-element loop.
     constexpr bool FAST = sizeof(TIN) == 2;
-    constexpr int NV = PERM ? 2 : 4, VW = PERM ? 8 : 4;     // 16-byte stores per fragment row, columns per store
+    constexpr int NV = PERM ? FN / 2 : FN, VW = PERM ? 8 : 4;     // 16-byte stores per fragment row, columns per store
+    constexpr int VS = WN / NV;                                    // column distance between a lane's stores
     TOUT* Cb = (TOUT*)g.C + (z0 * g.sC0 + z1 * g.sC1);
     const float* Rb = g.residual ? g.residual + (z0 * g.sR0 + z1 * g.sR1) : nullptr;
-    const int wrow0 = row0 + wr * (16 * FM), wcol0 = col0 + wc * 64;
-    const bool inside = wcol0 + 64 <= g.N;       // rows beyond M are masked per lane in the fast variants
+    const int wrow0 = row0 + wr * (16 * FM), wcol0 = col0 + wc * WN;
+    const bool inside = wcol0 + WN <= g.N;       // rows beyond M are masked per lane in the fast variants
     const bool aligned = (g.ldc % VW == 0) && (((uintptr_t)Cb) % 16 == 0) &&
                          (!Rb || ((g.ldr % 4 == 0) && (((uintptr_t)Rb) % 16 == 0)));
 
     auto fast = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;    // 0 plain, 1 QuickGELU, 2 residual add, 3 erf GELU, 4 ReLU
-        const int lcol = wcol0 + VW * kq;                  // store v of a row starts at lcol + v * (64 / NV)
+        const int lcol = wcol0 + VW * kq;                  // store v of a row starts at lcol + v * VS
         float bias_[NV][VW], gam_[NV][VW];
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
-                bias_[v][e] = g.bias ? g.bias[lcol + v * (64 / NV) + e] : 0.f;
-                gam_[v][e] = g.gamma ? g.gamma[lcol + v * (64 / NV) + e] : 1.f;
+                bias_[v][e] = g.bias ? g.bias[lcol + v * VS + e] : 0.f;
+                gam_[v][e] = g.gamma ? g.gamma[lcol + v * VS + e] : 1.f;
             }
         TOUT* cp = Cb + (int64_t)(wrow0 + r16) * g.ldc + lcol;
         // residual rows are requested PD - 1 fragment rows ahead of their use, in the registers the
@@ -269,7 +320,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
                     for (int q = 0; q < VW / 4; ++q)
-                        res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * (64 / NV) + 4 * q);
+                        res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * VS + 4 * q);
             }
         };
         if constexpr (MODE == 2) {
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                     if constexpr (MODE == 2) y += res[m % PD][v][e >> 2][e & 3];
                     x[e] = y;
                 }
-                TOUT* c = cp + (int64_t)m * 16 * g.ldc + v * (64 / NV);
+                TOUT* c = cp + (int64_t)m * 16 * g.ldc + v * VS;
                 if (16 * m < rows_left) {
                     if constexpr (sizeof(TOUT) == 4) {
                         *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
@@ -321,7 +372,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     else if (inside && aligned && g.act == 3 && !Rb) fast(std::integral_constant<int, 4>{});
     else {
         constexpr int EP_LD = FN * 16 + 4;
-        constexpr int CPL = 16 / (int)sizeof(TOUT), LPR = 64 / CPL, RPP = 64 / LPR, NPASS = 32 / RPP;
+        constexpr int CPL = 16 / (int)sizeof(TOUT), LPR = WN / CPL, RPP = 64 / LPR, NPASS = 32 / RPP;
         static_assert(NWAVES * 32 * EP_LD * 4 <= RING * STAGE, "epilogue staging does not fit");
         float* ep = (float*)lds + wave * 32 * EP_LD;
         const int ec = (lane % LPR) * CPL, er = lane / LPR;
@@ -367,16 +418,16 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
 // M-tiles per raster group (tuning knob of the diagnostic tools)
 int mars_ring_group_m = 8;
 
-template <int NWR, int NWC, int FM, int WPE>
+template <int NWR, int NWC, int FM, int FN, int WPE>
 static void ring_launch(const MarsGemm& g, hipStream_t s) {
-    constexpr int BM = 16 * FM * NWR, BN = 64 * NWC;
+    constexpr int BM = 16 * FM * NWR, BN = 16 * FN * NWC;
     dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(64 * NWR * NWC);
     if (g.in_dtype == 1) {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
     } else {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
     }
 }
 
@@ -384,8 +435,8 @@ static void ring_launch(const MarsGemm& g, hipStream_t s) {
 // 2: 128 x 128 (4 waves of 64 x 64, three per CU) for products with few tiles; 3: 64 x 128 (4 waves of
 // 32 x 64) for products that would not even give every CU a 128 x 128 tile
 void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape) {
-    if (shape == 0) ring_launch<2, 4, 8, 2>(g, s);
-    else if (shape == 1) ring_launch<2, 2, 8, 2>(g, s);
-    else if (shape == 2) ring_launch<2, 2, 4, 3>(g, s);
-    else ring_launch<2, 2, 2, 4>(g, s);
+    if (shape == 0) ring_launch<2, 4, 8, 4, 2>(g, s);
+    else if (shape == 1) ring_launch<2, 2, 8, 4, 2>(g, s);
+    else if (shape == 2) ring_launch<2, 2, 4, 4, 3>(g, s);
+    else ring_launch<2, 2, 2, 4, 4>(g, s);
 }
