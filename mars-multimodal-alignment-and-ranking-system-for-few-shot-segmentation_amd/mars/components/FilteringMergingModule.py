@@ -42,6 +42,8 @@ class FilteringMergingModule:
         self._tables: Dict = {}
         self._ws: Dict = {}
         self.last = {}
+        self._side: Optional[torch.cuda.Stream] = None
+        self._prefetched: Optional[dict] = None
 
     # ---------------------------------------------------------------- tables / buffers
     def _aa_table(self, n_in, n_out):
@@ -92,6 +94,25 @@ class FilteringMergingModule:
         self._score_proposals(query_img, mask_proposals, support_mask, cost_matrix, patch_features_spatial_dimension,
                               vva, vta, text)
         return self._merge_masks(mask_proposals)
+
+    def prefetch(self, query_img, mask_proposals, text: List[str]):
+        """Queues the AlphaCLIP text / visual features on a side stream.  They depend only on the query
+        image, the proposals and the prompt, so the caller can start them before the two alignment towers
+        run: their many small launches then fill the CUs the big batch leaves idle at its tile tails.
+        ``_score_proposals`` picks the result up when it is handed the same proposals and prompt."""
+        dev = self.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        masks = mask_proposals.to(dev).contiguous().float()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            tfeat = self._compute_alphaclip_text_feats(text)
+            feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._prefetched = dict(key=(mask_proposals.data_ptr(), tuple(mask_proposals.shape), tuple(text)), masks=masks,
+                                tfeat=tfeat, feats=feats, done=done)
 
     def _compute_alphaclip_text_feats(self, text: List[str]) -> torch.Tensor:
         """Lines 171-181 (normalisation happens inside the cosine-score kernel)."""
@@ -147,9 +168,13 @@ class FilteringMergingModule:
         ops.proposal_stats(w["bits"], N, P, vva.to(dev).contiguous().float().view(-1), vta.to(dev).contiguous().float().view(-1),
                            w["cnt"], w["svv"], w["svt"], w["ucnt"])
         # lines 90-97: AlphaCLIP text/visual features and their cosine (queued on the GPU ...)
-        tfeat = self._compute_alphaclip_text_feats(text)
-        feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w)
-        ops.cosine_scores(feats, tfeat, w["aclip"])
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre["key"] == (mask_proposals.data_ptr(), tuple(mask_proposals.shape), tuple(text)):
+            tfeat, feats, joined = pre["tfeat"], pre["feats"], pre["done"]
+        else:
+            tfeat = self._compute_alphaclip_text_feats(text)
+            feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w)
+            joined = None
         # lines 112-116, 142-169: ... while the host solves the N transport problems
         ev.synchronize()
         if isinstance(cost_matrix, SimilarityHandle):
@@ -158,6 +183,9 @@ class FilteringMergingModule:
             cm = cost_matrix.detach().cpu().float().contiguous()
             emd = ops.emd_scores_host(cm, w["fg_host"], w["bits_host"], self.emd_threads, is_cost=True)
         w["emd"].copy_(emd, non_blocking=False)
+        if joined is not None:
+            torch.cuda.current_stream(dev).wait_event(joined)
+        ops.cosine_scores(feats, tfeat, w["aclip"])
         # lines 118-138, 213-217: combine, rank, keep
         ops.rank(w["emd"], w["aclip"], w["cnt"], w["svv"], w["svt"], w["ucnt"], N, self.alpha, self.static_threshold,
                  self.dynamic_threshold, w["score"], w["order"], w["keep"])
