@@ -49,8 +49,12 @@ typedef struct MarsGemm {
 int marship_gemm(const MarsGemm* g, void* stream);
 /* Tuning hook (no reference counterpart): selects the GEMM kernel variant, returns the previous
  * one. 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
- * 3 = LDS-DMA ring 256x256, 4 = chosen by shape (default). */
+ * 3 = LDS-DMA ring 256x256, 4 = chosen by shape (default), 5 = ring 256x128, 6 = ring 128x128,
+ * 7 = ring 64x128. */
 int marship_set_gemm_variant(int variant);
+/* The variant marship_gemm would run for this product (5, 6 or 7 under "chosen by shape"); used by the
+ * benchmark to attribute launch times to kernels.  No reference counterpart. */
+int marship_gemm_variant_for(const MarsGemm* g);
 
 /* ---- ViT glue ------------------------------------------------------------------ */
 /* nn.LayerNorm over the last dim (dinov2 vision_transformer.py:97 eps 1e-6; clip/model.py:265-271

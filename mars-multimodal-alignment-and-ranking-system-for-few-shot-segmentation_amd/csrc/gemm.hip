@@ -171,6 +171,27 @@ extern "C" int marship_set_gemm_variant(int v) {
     return old;
 }
 
+// the kernel variant the launch policy picks for a product (the variant set by the tuning hook, or, for
+// "choose by shape", the ring shape: 5, 6 or 7)
+static int pick_variant(const MarsGemm* g) {
+    int v = g_gemm_variant;
+    if (v == 4) {
+        // the 256 x 128 ring shape needs about a full wave of workgroups to pay off; below that
+        // the 128 x 128 shape spreads the product over more CUs
+        const int64_t big = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256) * g->nb0 * g->nb1;
+        v = big >= 192 ? 5 : 6;
+        // fewer 128 x 128 tiles than about half the CUs: halve the tile height to spread the work
+        const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128) * g->nb0 * g->nb1;
+        if (v == 6 && t128 < 150) v = 7;
+    }
+    return v;
+}
+
+extern "C" int marship_gemm_variant_for(const MarsGemm* g) {
+    MARS_CHECK(g && g->M > 0 && g->N > 0 && g->nb0 > 0 && g->nb1 > 0, "gemm_variant_for: bad shape");
+    return pick_variant(g);
+}
+
 extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     MARS_CHECK(g && g->A && g->B && g->C, "gemm: null operand");
     MARS_CHECK(g->M > 0 && g->N > 0 && g->K > 0 && g->nb0 > 0 && g->nb1 > 0, "gemm: bad shape M=%d N=%d K=%d", g->M, g->N, g->K);
@@ -189,16 +210,7 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     dim3 grid(ntm * ntn, g->nb0 * g->nb1), block(THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (g_gemm_variant != 0) {
-        int v = g_gemm_variant;
-        if (v == 4) {
-            // the 256 x 128 ring shape needs about a full wave of workgroups to pay off; below that
-            // the 128 x 128 shape spreads the product over more CUs
-            const int64_t big = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256) * g->nb0 * g->nb1;
-            v = big >= 192 ? 5 : 6;
-            // fewer 128 x 128 tiles than about half the CUs: halve the tile height to spread the work
-            const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128) * g->nb0 * g->nb1;
-            if (v == 6 && t128 < 150) v = 7;
-        }
+        const int v = pick_variant(g);
         if (v == 3 || v >= 5) mars_gemm_ring_launch(*g, s, v == 3 ? 0 : v - 4);
         else mars_gemm_glds_launch(*g, s, v);
         MARS_LAUNCH_CHECK();

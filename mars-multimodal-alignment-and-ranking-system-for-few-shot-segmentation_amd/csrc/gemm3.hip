@@ -13,8 +13,8 @@
 //
 //     top of step s:  s_waitcnt vmcnt(n)   this wave's DMAs of step s+1 have landed (s+2 still flying)
 //                     s_barrier            => every wave's have, and everybody is done reading step s
-//                     issue DMAs of step s+3 into the slot step s used
-//                     12 x ds_read_b128 of step s+1 into the idle fragment registers,
+//                     DMAs of step s+3 into the slot step s used, dealt out between the MFMA rows
+//                     12 x ds_read_b128 of step s+1 into the idle fragment registers, likewise,
 //                     32 MFMAs on the fragments of step s (fetched one step earlier)
 //
 // Bank swizzle (rows are 64 B, four 16-B chunks): chunk c of row r sits at chunk slot
@@ -55,7 +55,6 @@ __device__ unsigned long long* mars_stamp_buf;
 namespace {
 
 constexpr int STEP_B = 64;                               // bytes of K per row and step
-constexpr int RING = 3;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -97,7 +96,7 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
 
 // NWR x NWC waves, each FM x FN fragments (16 FM x 16 FN outputs); WPE = waves per SIMD the register
 // budget must allow (workgroups per CU x waves per workgroup / 4).
-template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE>
+template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE, int RING>
 __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g, int group_m) {
     constexpr int BM = 16 * FM * NWR, WN = 16 * FN, BN = WN * NWC, NWAVES = NWR * NWC;
     constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
@@ -230,16 +229,16 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     {                                                                                                 \
         const int nslot = slot + 1 == RING ? 0 : slot + 1;                                            \
         if (MAIN || (s_) + 1 < ns) {                                                                  \
-            if (MAIN || (s_) + 2 < ns) MARS_WAIT_VM(PIECES);                                          \
+            if (MAIN || (s_) + RING - 1 < ns) MARS_WAIT_VM((RING - 2) * PIECES);                      \
             else MARS_WAIT_VM(0);                                                                     \
             __builtin_amdgcn_s_barrier();                                                             \
             asm volatile("" ::: "memory");                                                            \
         }                                                                                             \
-        const bool more = MARS_EXP_DMA && (MAIN || (s_) + 3 < ns);                                    \
+        const bool more = MARS_EXP_DMA && (MAIN || (s_) + RING < ns);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         auto row = [&](auto mi_tag) {                                                                 \
             constexpr int M_ = decltype(mi_tag)::value;                                               \
-            if (more) issue_row((s_) + 3, slot, mi_tag);                                              \
+            if (more) issue_row((s_) + RING, slot, mi_tag);                                           \
             if (MARS_EXP_READ) {                                                                      \
                 [&]<int... J>(std::integer_sequence<int, J...>) {                                     \
                     ((J * FM / (FM + FN) == M_ ? read_one(NA, NB, nslot, std::integral_constant<int, J>{}) : (void)0), ...); \
@@ -256,11 +255,10 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         slot = nslot;                                                                                 \
     }
 
-    issue(0, 0);
-    if (ns > 1) issue(1, 1);
-    if (ns > 2) issue(2, 2);
-    if (ns > 2) MARS_WAIT_VM(2 * PIECES);
-    else if (ns > 1) MARS_WAIT_VM(PIECES);
+#pragma unroll
+    for (int i = 0; i < RING; ++i)
+        if (i < ns) issue(i, i);
+    if (ns >= RING) MARS_WAIT_VM((RING - 1) * PIECES);
     else MARS_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -418,16 +416,16 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
 // M-tiles per raster group (tuning knob of the diagnostic tools)
 int mars_ring_group_m = 8;
 
-template <int NWR, int NWC, int FM, int FN, int WPE>
+template <int NWR, int NWC, int FM, int FN, int WPE, int RING>
 static void ring_launch(const MarsGemm& g, hipStream_t s) {
     constexpr int BM = 16 * FM * NWR, BN = 16 * FN * NWC;
     dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(64 * NWR * NWC);
     if (g.in_dtype == 1) {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
     } else {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, FN, WPE>), grid, block, 0, s, g, mars_ring_group_m);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
     }
 }
 
@@ -435,8 +433,8 @@ static void ring_launch(const MarsGemm& g, hipStream_t s) {
 // 2: 128 x 128 (4 waves of 64 x 64, three per CU) for products with few tiles; 3: 64 x 128 (4 waves of
 // 32 x 64) for products that would not even give every CU a 128 x 128 tile
 void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape) {
-    if (shape == 0) ring_launch<2, 4, 8, 4, 2>(g, s);
-    else if (shape == 1) ring_launch<2, 2, 8, 4, 2>(g, s);
-    else if (shape == 2) ring_launch<2, 2, 4, 4, 3>(g, s);
-    else ring_launch<2, 2, 2, 4, 4>(g, s);
+    if (shape == 0) ring_launch<2, 4, 8, 4, 2, 3>(g, s);
+    else if (shape == 1) ring_launch<2, 2, 8, 4, 2, 3>(g, s);
+    else if (shape == 2) ring_launch<2, 2, 4, 4, 3, 3>(g, s);
+    else ring_launch<2, 2, 2, 4, 4, 3>(g, s);
 }

@@ -17,7 +17,7 @@ from .hip import BF16, F32, MarsGemm
 _vp = ctypes.c_void_p
 
 # When bench.py sets GEMM_PROFILE to a list, every GEMM launch of dtype GEMM_PROFILE_DTYPE is
-# bracketed by timing events and (start, end, flops) is appended.
+# bracketed by timing events and (start, end, flops, kernel variant) is appended.
 GEMM_PROFILE = None
 GEMM_PROFILE_DTYPE = BF16
 
@@ -93,7 +93,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: i
         e0.record()
         hip.check(hip.lib().marship_gemm(ctypes.byref(g), stream()), "marship_gemm")
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * nb0 * nb1))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * nb0 * nb1, hip.lib().marship_gemm_variant_for(ctypes.byref(g))))
         return
     hip.check(hip.lib().marship_gemm(ctypes.byref(g), stream()), "marship_gemm")
 

@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     
     
     if (argc > 7) mars_ring_group_m = atoi(argv[7]);
-    const int BMt = shape == 2 ? 128 : 256, BN = shape == 0 ? 256 : 128, NW = shape == 0 ? 8 : 4;
+    const int BMt = (shape == 2 || shape == 4) ? 128 : (shape == 3 || shape == 5) ? 64 : 256, BN = shape == 0 ? 256 : 128, NW = shape == 0 ? 8 : 4;
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
     unsigned x = 12345u;
     for (auto& v : ha) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((x >> 9) & 0x3ffu) + ((x >> 3) & 0x8000u)); }

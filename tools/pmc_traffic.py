@@ -3,6 +3,8 @@ its own over the same command):
 
     python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel substr> <out.json>
 
+<kernel substr> may hold alternatives separated by '|' (a kernel name has to contain one of them).
+
 Both counters are reported in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of wide
 (16 B per lane) streaming reads at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte
 per lane stores.  Infinity-Cache hits are included in both (they are fabric-side counters)."""
@@ -16,7 +18,7 @@ def per_kernel(path, counter, sub):
     tot, n = 0.0, 0
     byname = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and sub in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and any(a in r["Kernel_Name"] for a in sub.split("|")):
             v = float(r["Counter_Value"])
             tot += v
             n += 1
