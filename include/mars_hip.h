@@ -223,6 +223,10 @@ int marship_threshold_masks(const float* in, float thr, float* out, int64_t n, v
  * host pointers; keep receives the surviving indices by decreasing score. */
 int marshost_box_nms(const float* boxes, const float* scores, int n, float iou_threshold, int32_t* keep,
                      int32_t* nkeep);
+/* scipy.optimize.linear_sum_assignment as the prompt-sampling stage calls it (matcher/Matcher.py:449-450,
+ * 471-472, 364-365, 376): w is a host f32 [n, m] matrix with row stride ld; row_ind / col_ind receive
+ * min(n, m) pairs ordered by row.  Returns the pair count, negative on error (non-finite entries). */
+int marshost_lap(const float* w, int64_t ld, int n, int m, int maximize, int64_t* row_ind, int64_t* col_ind);
 
 /* ---- GradCAM backward pieces ----------------------------------------------------- */
 /* LayerNorm backward w.r.t. the input: dx = add + LN'(x)[dy*w].  dy row r is dy + r*dy_stride

@@ -1,2 +1,2 @@
-"""Matcher pieces that share the ranking path's kernels (features, similarity, per-mask scores)."""
-from .Matcher import Matcher, RobustPromptSampler, build_matcher_oss  # noqa: F401
+"""The Matcher (proposal producer of the reference) on the ranking path's kernels."""
+from .Matcher import Matcher, MatcherProposals, RobustPromptSampler, build_matcher_oss, kmeans_pp  # noqa: F401

@@ -542,3 +542,18 @@ def box_nms_host(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float
     hip.check(hip.lib().marshost_box_nms(_vp(b.data_ptr()), _vp(s.data_ptr()), n, float(iou_threshold), _vp(keep.data_ptr()), ctypes.byref(cnt)),
               "marshost_box_nms")
     return keep[: cnt.value].long()
+
+
+def lap_host(weights: torch.Tensor, maximize: bool = False):
+    """Rectangular linear assignment on a host f32 matrix: (row_ind, col_ind) int64, min(n, m) pairs by row."""
+    w = weights.detach().cpu().float()
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    _req(w.dim() == 2 and w.shape[0] > 0 and w.shape[1] > 0, "lap_host: weights must be a non-empty matrix")
+    n, m = w.shape
+    k = min(n, m)
+    rows, cols = torch.empty(k, dtype=torch.int64), torch.empty(k, dtype=torch.int64)
+    rc = hip.lib().marshost_lap(_vp(w.data_ptr()), w.stride(0), n, m, int(bool(maximize)), _vp(rows.data_ptr()), _vp(cols.data_ptr()))
+    if rc < 0:
+        hip.check(rc, "marshost_lap")
+    return rows, cols

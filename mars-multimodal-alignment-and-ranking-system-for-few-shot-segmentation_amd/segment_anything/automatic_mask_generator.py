@@ -30,9 +30,11 @@ def build_point_grid(n_per_side: int) -> np.ndarray:
 
 class SamAutomaticMaskGenerator:
     def __init__(self, model: Sam, points_per_side: Optional[int] = 32, points_per_batch: int = 64, pred_iou_thresh: float = 0.88,
-                 stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0, box_nms_thresh: float = 0.7,
+                 sel_pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0,
+                 sel_stability_score_thresh: float = 0.95, sel_stability_score_offset: float = 1.0, box_nms_thresh: float = 0.7,
                  crop_n_layers: int = 0, point_grids: Optional[List[np.ndarray]] = None, min_mask_region_area: int = 0,
-                 output_mode: str = "binary_mask", multimask_output: bool = True, **unused):
+                 output_mode: str = "binary_mask", multimask_output: bool = True, sel_multimask_output: bool = True,
+                 output_layer: int = -1, sel_output_layer: int = -1, dense_pred: bool = True, **unused):
         assert (points_per_side is None) != (point_grids is None), "Exactly one of points_per_side or point_grid must be provided."
         if crop_n_layers != 0 or min_mask_region_area != 0 or output_mode != "binary_mask":
             raise NotImplementedError("one crop layer, binary masks, no small-region post-processing")
@@ -42,31 +44,45 @@ class SamAutomaticMaskGenerator:
         self.pred_iou_thresh = pred_iou_thresh
         self.stability_score_thresh = stability_score_thresh
         self.stability_score_offset = stability_score_offset
+        self.sel_pred_iou_thresh = sel_pred_iou_thresh
+        self.sel_stability_score_thresh = sel_stability_score_thresh
+        self.sel_stability_score_offset = sel_stability_score_offset
         self.box_nms_thresh = box_nms_thresh
         self.multimask_output = multimask_output
+        self.sel_multimask_output = sel_multimask_output
+        self.output_layer = output_layer
+        self.sel_output_layer = sel_output_layer
+        self.dense_pred = dense_pred
         self.stored_features: Dict[Any, Any] = {}
 
     def reset_stored_features(self):
         self.stored_features = {}
 
-    # ------------------------------------------------------------------ lines 385-453
-    def _process_batch(self, points: np.ndarray, im_size, keep_lists: dict):
+    # ------------------------------------------------------------------ lines 385-453 and 455-556
+    def _pick_layers(self, layer: int, masks, iou, low):
+        """Output selection shared by both prompt paths (lines 405-415, 508-518; both test sel_multimask_output)."""
+        if self.sel_multimask_output:
+            if layer in (0, 1, 2):
+                return masks[:, layer:layer + 1], iou[:, layer:layer + 1], low[:, layer:layer + 1]
+            if layer in (3, 4, 5):
+                return masks[:, layer - 3:], iou[:, layer - 3:], low[:, layer - 3:]
+        return masks, iou, low
+
+    def _keep_batch(self, masks, iou, low, points: list, iou_thresh: float, stab_thresh: float, stab_off: float, keep_lists: dict):
+        """masks [B, C, H, W] logits: one statistics launch, the two filters on the host, survivors kept as
+        {0,1} floats on the GPU.  ``points`` holds the prompt points of every batch row."""
         pr, dev = self.predictor, self.predictor.device
-        oh, ow = im_size
-        tp = torch.as_tensor(pr.transform.apply_coords(points, im_size), dtype=torch.float32, device=dev)
-        labels = torch.ones(tp.shape[0], 1, dtype=torch.int32, device=dev)
-        masks, iou, low = pr.predict_torch(tp[:, None, :], labels, multimask_output=self.multimask_output, return_logits=True)
         nm = masks.shape[1]
-        masks, iou, low = masks.flatten(0, 1), iou.flatten(0, 1), low.flatten(0, 1)
+        masks, iou, low = masks.flatten(0, 1).contiguous(), iou.flatten(0, 1), low.flatten(0, 1)
         stats = torch.empty(masks.shape[0], 6, dtype=torch.int32, device=dev)
-        ops.mask_stats(masks, pr.model.mask_threshold, self.stability_score_offset, stats)
+        ops.mask_stats(masks, pr.model.mask_threshold, stab_off, stats)
         st, iou_h = stats.cpu(), iou.cpu()
         stab = st[:, 0].float() / st[:, 1].float()                    # intersections / unions (amg.py:173)
         keep = torch.ones(masks.shape[0], dtype=torch.bool)
-        if self.pred_iou_thresh > 0.0:
-            keep &= iou_h > self.pred_iou_thresh
-        if self.stability_score_thresh > 0.0:
-            keep &= stab >= self.stability_score_thresh
+        if iou_thresh > 0.0:
+            keep &= iou_h > iou_thresh
+        if stab_thresh > 0.0:
+            keep &= stab >= stab_thresh
         idx = torch.nonzero(keep).flatten()
         if idx.numel() == 0:
             return
@@ -78,36 +94,71 @@ class SamAutomaticMaskGenerator:
         keep_lists["iou"].append(iou_h[idx])
         keep_lists["stab"].append(stab[idx])
         keep_lists["boxes"].append(st[idx, 2:6].float())
-        keep_lists["points"].append(torch.as_tensor(points.repeat(nm, axis=0))[idx])
+        keep_lists["points"].extend(points[int(i) // nm] for i in idx.tolist())      # rows repeat once per output mask
         keep_lists["low"].append(low[sel])
 
+    def _process_batch(self, points: np.ndarray, im_size, keep_lists: dict):
+        pr, dev = self.predictor, self.predictor.device
+        tp = torch.as_tensor(pr.transform.apply_coords(points, im_size), dtype=torch.float32, device=dev)
+        labels = torch.ones(tp.shape[0], 1, dtype=torch.int32, device=dev)
+        masks, iou, low = pr.predict_torch(tp[:, None, :], labels, multimask_output=self.multimask_output, return_logits=True)
+        masks, iou, low = self._pick_layers(self.output_layer, masks, iou, low)
+        self._keep_batch(masks, iou, low, [[p] for p in points.tolist()], self.pred_iou_thresh, self.stability_score_thresh,
+                         self.stability_score_offset, keep_lists)
+
+    def _process_sel_batch(self, im_size, point_coords: np.ndarray, point_labels: np.ndarray, keep_lists: dict):
+        """One batch of prompts of k points each: point_coords [B, k, 2] in image pixels, point_labels [B, k]."""
+        pr, dev = self.predictor, self.predictor.device
+        point_coords = np.asarray(point_coords)
+        if point_coords.ndim == 2:
+            point_coords, point_labels = point_coords[None], np.asarray(point_labels)[None]
+        tp = torch.as_tensor(pr.transform.apply_coords(point_coords, im_size), dtype=torch.float32, device=dev)
+        labels = torch.as_tensor(np.asarray(point_labels), dtype=torch.int32, device=dev)
+        masks, iou, low = pr.predict_torch(tp, labels, multimask_output=self.sel_multimask_output, return_logits=True)
+        masks, iou, low = self._pick_layers(self.sel_output_layer, masks, iou, low)
+        self._keep_batch(masks, iou, low, point_coords.tolist(), self.sel_pred_iou_thresh, self.sel_stability_score_thresh,
+                         self.sel_stability_score_offset, keep_lists)
+
     # ------------------------------------------------------------------ lines 160-243, 295-383
-    def _run(self, image: np.ndarray) -> dict:
+    def _run(self, image: np.ndarray, select_point_coords=None, select_point_labels=None, select_box=None,
+             select_mask_input=None) -> dict:
+        if select_box is not None or select_mask_input is not None:
+            raise NotImplementedError("box and mask prompts are not built; point prompts only")
         oh, ow = image.shape[:2]
         self.predictor.set_image(image)
-        pts_all = self.point_grids[0] * np.array([[ow, oh]], dtype=np.float64)
         lists = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
-        for b0 in range(0, len(pts_all), self.points_per_batch):
-            self._process_batch(pts_all[b0:b0 + self.points_per_batch], (oh, ow), lists)
+        if self.dense_pred:
+            pts_all = self.point_grids[0] * np.array([[ow, oh]], dtype=np.float64)
+            for b0 in range(0, len(pts_all), self.points_per_batch):
+                self._process_batch(pts_all[b0:b0 + self.points_per_batch], (oh, ow), lists)
+        if select_point_coords is not None:
+            assert select_point_labels is not None, "select_point_labels should not be None !"
+            for coords, labels in zip(select_point_coords, select_point_labels):     # one array per prompt size
+                for b0 in range(0, len(coords), self.points_per_batch):
+                    self._process_sel_batch((oh, ow), coords[b0:b0 + self.points_per_batch],
+                                            labels[b0:b0 + self.points_per_batch], lists)
         self.predictor.reset_image()
         if not lists["iou"]:
             return dict(masks=torch.zeros(0, oh, ow, device=self.predictor.device), iou=torch.zeros(0), stab=torch.zeros(0),
-                        boxes=torch.zeros(0, 4), points=torch.zeros(0, 2), low=None, size=(oh, ow))
+                        boxes=torch.zeros(0, 4), points=[], low=None, size=(oh, ow))
+        points = lists.pop("points")
         cat = {k: torch.cat(v, dim=0) for k, v in lists.items()}
         keep = ops.box_nms_host(cat["boxes"], cat["iou"], self.box_nms_thresh)
-        out = {k: (v[keep.to(v.device)] if torch.is_tensor(v) else v) for k, v in cat.items()}
+        out = {k: v[keep.to(v.device)] for k, v in cat.items()}
+        out["points"] = [points[i] for i in keep.tolist()]
         out["size"] = (oh, ow)
         return out
 
-    def generate(self, image: np.ndarray) -> List[Dict[str, Any]]:
-        r = self._run(image)
+    def generate(self, image: np.ndarray, select_point_coords=None, select_point_labels=None, select_box=None,
+                 select_mask_input=None) -> List[Dict[str, Any]]:
+        r = self._run(image, select_point_coords, select_point_labels, select_box, select_mask_input)
         oh, ow = r["size"]
         recs = []
         masks_h = r["masks"].cpu().numpy() > 0 if len(r["iou"]) else np.zeros((0, oh, ow), bool)
         for i in range(len(r["iou"])):
             x0, y0, x1, y1 = [float(v) for v in r["boxes"][i].tolist()]
             recs.append({"segmentation": masks_h[i], "area": int(masks_h[i].sum()), "bbox": [x0, y0, x1 - x0, y1 - y0],
-                         "predicted_iou": float(r["iou"][i]), "point_coords": [r["points"][i].tolist()],
+                         "predicted_iou": float(r["iou"][i]), "point_coords": r["points"][i],
                          "low_res_masks": r["low"][i].cpu().numpy(), "stability_score": float(r["stab"][i]),
                          "crop_box": [0.0, 0.0, float(ow), float(oh)]})
         return recs

@@ -98,3 +98,185 @@ def clip_pipeline_process_masks(aclip_sd, aclip_kw: dict, target_img: torch.Tens
         f = f / f.norm(dim=-1, keepdim=True)
         out[idx] = (100.0 * f @ text.t()).numpy()
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# prompt-sampling stage (Matcher.predict): scipy's linear_sum_assignment is the reference's own solver,
+# so the assignment step is pinned; the rest follows /root/reference/matcher/Matcher.py
+# ----------------------------------------------------------------------------------------
+def _inds_to_points(inds: torch.Tensor, g: int, patch: int, input_size) -> np.ndarray:
+    """Lines 512-547: duplicates removed through a Python set, patch centres, points outside dropped."""
+    uniq = torch.tensor(list(set(inds.cpu().tolist())))
+    xs = ((uniq % g) * patch + patch // 2).tolist()
+    ys = ((uniq // g) * patch + patch // 2).tolist()
+    out = []
+    for x, y in zip(xs, ys):
+        if int(x) < input_size[1] and int(y) < input_size[0]:
+            out.append([int(x), int(y)])
+    return np.array(out)
+
+
+def negatives_from_discarded(idxs_forward, sim_scores_forward, idxs_reverse, idxs_mask, g, patch, input_size):
+    """Lines 304-348."""
+    discarded_ind = torch.isin(idxs_reverse[1], idxs_mask, invert=True)
+    if (discarded_ind == False).all().item():  # noqa: E712
+        return None, None
+    cols = idxs_forward[1][discarded_ind]
+    sims = sim_scores_forward[discarded_ind]
+    n = len(sims) // 2 if len(sims) > 40 else len(sims)
+    _, order = torch.sort(sims, descending=False)
+    return _inds_to_points(cols[order[:n]], g, patch, input_size), n
+
+
+def negatives_from_cost(C: torch.Tensor, idxs_mask, g, patch, input_size):
+    """Lines 350-417 (the sorted positions of the filtered costs index the unfiltered column list, as there)."""
+    from scipy.optimize import linear_sum_assignment
+    fwd = [torch.as_tensor(i, dtype=torch.int64) for i in linear_sum_assignment(C, maximize=True)]
+    cost_f = C[fwd[0], fwd[1]]
+    rev = [torch.as_tensor(i, dtype=torch.int64) for i in linear_sum_assignment(C.t()[fwd[1]], maximize=True)]
+    retain = torch.isin(rev[1], idxs_mask, invert=True)
+    if not (retain == False).all().item():  # noqa: E712
+        cost_f = cost_f[retain]
+    n = len(cost_f) // 2 if len(cost_f) > 40 else len(cost_f)
+    _, order = torch.sort(cost_f, descending=True)
+    return _inds_to_points(fwd[1][order[:n]], g, patch, input_size), n
+
+
+def patch_level_matching(S: torch.Tensor, ref_masks_pool: torch.Tensor, g: int, patch: int, input_size,
+                         neg_from_discarded: bool = False, neg_from_cost: bool = False):
+    """Lines 419-577 (no box).  S [ns*P, P] on the CPU.  Returns (points, negatives-or-discarded, C, n, n_neg)."""
+    from scipy.optimize import linear_sum_assignment
+    C = (1 - S) / 2
+    fg = ref_masks_pool.flatten().bool()
+    S_forward = S[fg]
+    fwd = [torch.as_tensor(i, dtype=torch.int64) for i in linear_sum_assignment(S_forward, maximize=True)]
+    sim_f = S_forward[fwd[0], fwd[1]]
+    idx_mask = ref_masks_pool.flatten().nonzero()[:, 0]
+    S_reverse = S.t()[fwd[1]]
+    rev = [torch.as_tensor(i, dtype=torch.int64) for i in linear_sum_assignment(S_reverse, maximize=True)]
+    retain = torch.isin(rev[1], idx_mask)
+    pos, neg, sim_pos = fwd, fwd, sim_f.clone()
+    if not (retain == False).all().item():  # noqa: E712
+        pos = [fwd[0][retain], fwd[1][retain]]
+        neg = [fwd[0][~retain], fwd[1][~retain]]
+        sim_pos = sim_f[retain]
+    n = len(sim_pos) // 2 if len(sim_pos) > 40 else len(sim_pos)
+    _, order = torch.sort(sim_pos, descending=True)
+    points = _inds_to_points(pos[1][order[:n]], g, patch, input_size)
+    discarded = _inds_to_points(neg[1], g, patch, input_size)
+    priors, n_neg = [], []
+    if neg_from_discarded:
+        p, k = negatives_from_discarded(fwd, sim_f, rev, idx_mask, g, patch, input_size)
+        priors.append(p); n_neg.append(k)
+    if neg_from_cost:
+        p, k = negatives_from_cost(C, idx_mask, g, patch, input_size)
+        priors.append(p); n_neg.append(k)
+    return points, (priors if len(priors) > 0 else discarded), C, n, n_neg
+
+
+def _combinations(n: int, k: int):
+    """Lines 1212-1224."""
+    if k > n:
+        return []
+    if k == 0:
+        return [[]]
+    if k == n:
+        return [[i for i in range(n)]]
+    res = []
+    for i in range(n):
+        for j in _combinations(i, k - 1):
+            res.append(j + [i])
+    return res
+
+
+def sample_points(points, negative_points=None, sample_range=(4, 6), max_iterations: int = 30):
+    """Lines 1226-1295; draws from the ``random`` module in the reference's order."""
+    import random
+    sample_list, label_list = [], []
+    for i in range(min(sample_range[0], len(points)), min(sample_range[1], len(points)) + 1):
+        sample_neg = label_neg = None
+        if len(points) > 8:
+            index = [random.sample(range(len(points)), i) for j in range(max_iterations)]
+            sample = np.take(points, index, axis=0)
+            if negative_points is not None:
+                if len(negative_points) > 8:
+                    index_neg = [random.sample(range(len(negative_points)), i) for j in range(max_iterations)]
+                else:
+                    index_neg = [random.choices(range(len(negative_points)), k=i) for j in range(max_iterations)]
+                sample_neg = np.take(negative_points, index_neg, axis=0)
+                label_neg = np.zeros((sample_neg.shape[0], i))
+        else:
+            index = _combinations(len(points), i)
+            sample = np.take(points, index, axis=0)
+            if negative_points is not None:
+                index_neg = [random.choices(range(len(negative_points)), k=i) for j in range(len(index))]
+                sample_neg = np.take(negative_points, index_neg, axis=0)
+                label_neg = np.zeros((sample_neg.shape[0], i))
+        sample_list.append(sample)
+        label_list.append(np.ones((sample.shape[0], i)))
+        if sample_neg is not None:
+            sample_list.append(sample_neg)
+            label_list.append(label_neg)
+    if negative_points is not None:
+        pts = [np.hstack((sample_list[i], sample_list[i + 1])) for i in range(0, len(sample_list), 2)]
+        lbs = [np.hstack((label_list[i], label_list[i + 1])) for i in range(0, len(label_list), 2)]
+        return pts, lbs
+    return sample_list, label_list
+
+
+def mask_generation(sam_sd, sam_kw: dict, gen_kw: dict, tar_img_np: np.ndarray, points, all_points, ref_masks_pool, C, g: int,
+                    negative_points=None, *, use_neg: bool = False, merge_prompt_types: bool = False, sample_range=(4, 6),
+                    max_iterations: int = 30, alpha=1.0, beta=0.0, exp=0.0, score_filter_cfg=None, num_merging_mask=10):
+    """Lines 619-834 (no box, no cascaded mask input).  Returns (merged [1, H, W] float, score, unfiltered masks, merged-from)."""
+    from . import sam as osam
+    cfg = {"emd": 0.0, "purity": 0.0, "coverage": 0.0, "score_filter": False, "score": 0.33, "score_norm": 0.1,
+           "topk_scores_threshold": 0.0}
+    cfg.update(score_filter_cfg or {})
+    samples_list, label_list = [], []
+    if use_neg:
+        for negative_pts in negative_points:
+            if negative_pts is not None and len(negative_pts) > 0:
+                s, l = sample_points(points, negative_pts, sample_range, max_iterations)
+            else:
+                s, l = sample_points(points, None, sample_range, max_iterations)
+            samples_list.extend(s); label_list.extend(l)
+        if merge_prompt_types:
+            s, l = sample_points(points, None, sample_range, max_iterations)
+            samples_list.extend(s); label_list.extend(l)
+    else:
+        samples_list, label_list = sample_points(points, None, sample_range, max_iterations)
+    recs = osam.generate(sam_sd, sam_kw, tar_img_np, select_point_coords=samples_list, select_point_labels=label_list, **gen_kw)
+    tar_masks = np.stack([r["segmentation"] for r in recs])[:, None] > 0
+    coords = [r["point_coords"] for r in recs]
+    sc = matcher_scores(tar_masks, all_points, C, ref_masks_pool, g, alpha, beta, exp)
+    metric = {k: sc[k] for k in ("purity", "coverage", "emd")}
+    scores = sc["scores"]
+    pred = tar_masks[:, 0]
+    unfiltered = torch.tensor(pred.copy() > 0, dtype=torch.float)
+    for name in ["coverage", "emd", "purity"]:
+        if cfg[name] > 0:
+            thres = min(cfg[name], metric[name].max())
+            idx = torch.where(metric[name] >= thres)[0]
+            scores, pred = scores[idx], pred[idx.numpy()]
+            coords = [coords[int(i)] for i in idx]
+            metric = {k: v[idx] for k, v in metric.items()}
+    if cfg["score_filter"]:
+        distances, rank = torch.sort(1 - scores, descending=False)
+        norm = (distances - distances.min()) / (distances.max() + 1e-6)
+        f = distances < cfg["score"]
+        f[..., 0] = True
+        f = f * (norm < cfg["score_norm"])
+        chosen = rank[f][:num_merging_mask]
+        final = scores[chosen].mean()
+    else:
+        topk = min(num_merging_mask, scores.size(0))
+        topk_idx = scores.topk(topk)[1]
+        topk_scores = scores[topk_idx].numpy()
+        if cfg["topk_scores_threshold"] > 0:
+            topk_scores = topk_scores / topk_scores.max()
+        keep = topk_scores > cfg["topk_scores_threshold"]
+        chosen = topk_idx[torch.from_numpy(keep)]
+        final = topk_scores[keep].mean()
+    merged_from = pred[chosen.numpy()].reshape(-1, pred.shape[-2], pred.shape[-1])
+    merged = merged_from.sum(0) > 0
+    return torch.tensor(merged[None], dtype=torch.float), float(final), unfiltered, torch.tensor(merged_from.copy() > 0, dtype=torch.float)

@@ -332,35 +332,65 @@ def box_nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tens
 
 def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32, points_per_batch: int = 64,
              pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0,
-             box_nms_thresh: float = 0.7, mask_threshold: float = 0.0) -> List[dict]:
-    """SamAutomaticMaskGenerator.generate with one crop layer and the dense point grid
-    (automatic_mask_generator.py:160-243, 295-383, 385-453), binary-mask output."""
+             box_nms_thresh: float = 0.7, mask_threshold: float = 0.0, dense_pred: bool = True,
+             select_point_coords=None, select_point_labels=None, sel_pred_iou_thresh: float = 0.88,
+             sel_stability_score_thresh: float = 0.95, sel_stability_score_offset: float = 1.0,
+             multimask_output: bool = True, sel_multimask_output: bool = True, output_layer: int = -1,
+             sel_output_layer: int = -1) -> List[dict]:
+    """SamAutomaticMaskGenerator.generate with one crop layer: the dense point grid
+    (automatic_mask_generator.py:160-243, 295-383, 385-453) and / or the caller's prompt batches
+    (select_point_coords: list of [n, k, 2] arrays, one per prompt size; lines 332-365, 455-556);
+    binary-mask output."""
     oh, ow = image.shape[:2]
     state = set_image(sd, cfg, image)
-    pts_all = build_point_grid(points_per_side) * np.array([[ow, oh]], dtype=np.float64)
     recs = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
-    for b0 in range(0, len(pts_all), points_per_batch):
-        pts = pts_all[b0:b0 + points_per_batch]
-        tp = torch.as_tensor(apply_coords(pts, (oh, ow), cfg["img_size"]))
-        masks, iou, low = predict_torch(sd, cfg, state, tp[:, None, :], torch.ones(len(pts), 1, dtype=torch.int))
+
+    def pick(layer, *ts):
+        if sel_multimask_output and layer in (0, 1, 2):
+            return [t[:, layer:layer + 1] for t in ts]
+        if sel_multimask_output and layer in (3, 4, 5):
+            return [t[:, layer - 3:] for t in ts]
+        return list(ts)
+
+    def batch(coords, labels, plist, multi, layer, iou_thr, stab_thr, stab_off):
+        tp = torch.as_tensor(apply_coords(coords, (oh, ow), cfg["img_size"]))
+        masks, iou, low = predict_torch(sd, cfg, state, tp, torch.as_tensor(labels), multi)
+        masks, iou, low = pick(layer, masks, iou, low)
+        nm = masks.shape[1]
         masks, iou, low = masks.flatten(0, 1), iou.flatten(0, 1), low.flatten(0, 1)
-        points = torch.as_tensor(pts.repeat(3, axis=0))
-        keep = iou > pred_iou_thresh if pred_iou_thresh > 0.0 else torch.ones_like(iou, dtype=torch.bool)
-        masks, iou, low, points = masks[keep], iou[keep], low[keep], points[keep]
-        stab = stability_score(masks, mask_threshold, stability_score_offset)
-        if stability_score_thresh > 0.0:
-            keep = stab >= stability_score_thresh
-            masks, iou, low, points, stab = masks[keep], iou[keep], low[keep], points[keep], stab[keep]
-        bin_ = masks > mask_threshold
-        recs["masks"].append(bin_); recs["iou"].append(iou); recs["stab"].append(stab); recs["low"].append(low)
-        recs["boxes"].append(mask_to_box(bin_)); recs["points"].append(points)
-    cat = {k: torch.cat(v, dim=0) for k, v in recs.items()}
-    keep = box_nms(cat["boxes"].float(), cat["iou"], box_nms_thresh) if len(cat["iou"]) else torch.zeros(0, dtype=torch.int64)
+        points = [plist[i // nm] for i in range(masks.shape[0])]
+        keep = iou > iou_thr if iou_thr > 0.0 else torch.ones_like(iou, dtype=torch.bool)
+        stab = stability_score(masks, mask_threshold, stab_off)
+        if stab_thr > 0.0:
+            keep = keep & (stab >= stab_thr)
+        idx = torch.nonzero(keep).flatten().tolist()
+        bin_ = masks[idx] > mask_threshold
+        recs["masks"].append(bin_); recs["iou"].append(iou[idx]); recs["stab"].append(stab[idx]); recs["low"].append(low[idx])
+        recs["boxes"].append(mask_to_box(bin_)); recs["points"].extend(points[i] for i in idx)
+
+    if dense_pred:
+        pts_all = build_point_grid(points_per_side) * np.array([[ow, oh]], dtype=np.float64)
+        for b0 in range(0, len(pts_all), points_per_batch):
+            pts = pts_all[b0:b0 + points_per_batch]
+            batch(pts[:, None, :], np.ones((len(pts), 1), dtype=np.int64), [[p] for p in pts.tolist()], multimask_output,
+                  output_layer, pred_iou_thresh, stability_score_thresh, stability_score_offset)
+    if select_point_coords is not None:
+        for coords, labels in zip(select_point_coords, select_point_labels):
+            coords, labels = np.asarray(coords), np.asarray(labels)
+            for b0 in range(0, len(coords), points_per_batch):
+                c = coords[b0:b0 + points_per_batch]
+                batch(c, labels[b0:b0 + points_per_batch], c.tolist(), sel_multimask_output, sel_output_layer,
+                      sel_pred_iou_thresh, sel_stability_score_thresh, sel_stability_score_offset)
+    points = recs.pop("points")
+    cat = {k: torch.cat(v, dim=0) for k, v in recs.items()} if recs["iou"] else None
+    if cat is None or len(cat["iou"]) == 0:
+        return []
+    keep = box_nms(cat["boxes"].float(), cat["iou"], box_nms_thresh)
     out = []
     for i in keep.tolist():
         m = cat["masks"][i].numpy()
         x0, y0, x1, y1 = cat["boxes"][i].tolist()
         out.append(dict(segmentation=m, area=int(m.sum()), bbox=[x0, y0, x1 - x0, y1 - y0], predicted_iou=float(cat["iou"][i]),
-                        point_coords=[cat["points"][i].tolist()], low_res_masks=cat["low"][i].numpy(),
+                        point_coords=points[i], low_res_masks=cat["low"][i].numpy(),
                         stability_score=float(cat["stab"][i]), crop_box=[0, 0, ow, oh]))
     return out

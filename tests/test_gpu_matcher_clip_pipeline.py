@@ -51,7 +51,7 @@ def test_matcher_features_similarity_and_mask_scores(pkg, cuda, nshot):
     for k in ("purity", "coverage", "emd", "scores"):
         assert maxdiff(got[k], want[k]) < TOL, k
     assert torch.equal(m.get_unfiltered_generated_masks().cpu(), (masks > 0).float())
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                               # no mask generator was configured
         m.predict()
     # an all-zero reference mask gets the centred square (lines 150-153)
     m.clear()
@@ -117,3 +117,93 @@ def test_clip_pipeline_process_masks(pkg, cuda):
         pipe.predict()                                            # no class name and no VLM
     pipe.reset_clip_pipeline()
     assert gen.resets >= 1 and pipe.target_img is None
+
+
+@pytest.mark.parametrize("variant", ["plain", "negatives", "score_filter"])
+def test_matcher_predict_end_to_end(pkg, cuda, variant):
+    """Matcher.predict (assignment matching, prompt sets, SAM prompt batches, metric filters, merge) against the
+    oracle's restatement under equal seeds.  Parity unpinned except for the assignment step (scipy)."""
+    import random
+    from oracle import sam as osam
+    cfg = tiny_config(pkg, nshot=1)
+    a = cfg["args"]
+    a.device, a.sam_size = "cuda:0", "tiny"
+    a.alpha, a.beta, a.exp = 0.8, 0.3, 0.5
+    a.sample_range, a.max_sample_iterations, a.num_merging_mask = (1, 3), 6, 4
+    a.emd_filter, a.purity_filter, a.coverage_filter = 0.0, 0.02, 0.3
+    if variant == "negatives":
+        a.use_negative_priors_from_discarded, a.use_negative_priors_from_cost, a.merge_prompt_types = True, True, True
+    if variant == "score_filter":
+        a.use_score_filter, a.deep_score_filter, a.deep_score_norm_filter = True, 0.9, 0.8
+    scfg = pkg.synth.SAM_ARCHS["tiny"]
+    sam_sd = pkg.synth.sam_state_dict(scfg, seed=5)
+    ep = pkg.synth.make_episode(41, size=cfg["size"], nshot=1, nprop=2)
+    M = importlib.import_module(pkg.__name__ + ".matcher.Matcher")
+    m = M.build_matcher_oss(a, state_dict=cfg["sds"]["dino"], sam_state_dict=sam_sd)
+    m.set_reference(ep["support_imgs"].to(cuda), ep["support_masks"].to(cuda))
+    m.set_target(ep["query_img"].to(cuda))
+    G, size = cfg["size"] // 14, cfg["size"]
+    # matched points against the oracle (scipy assignment on the oracle's similarity)
+    om = cfg["oracle_models"]
+    o_ref, o_tar = omatch.extract_img_feats(om["dino_sd"], om["dino_kw"], ep["support_imgs"][0], ep["query_img"])
+    oS, _ = omatch.similarity_and_cost(o_ref, o_tar)
+    pool_ref = omatch.set_reference_pool(ep["support_masks"], 14)
+    neg = variant == "negatives"
+    want_pts, want_neg, oC, _, _ = omatch.patch_level_matching(oS, pool_ref, G, 14, (size, size), neg, neg)
+    got_pts, got_neg, _, _, _, _, _ = m.patch_level_matching()
+    assert np.array_equal(got_pts, want_pts) and len(got_pts) >= 1
+    if neg:
+        assert len(got_neg) == len(want_neg) == 2
+        for x, y in zip(got_neg, want_neg):
+            assert (x is None and y is None) or np.array_equal(x, y)
+    else:
+        assert np.array_equal(got_neg, want_neg)
+    random.seed(7)
+    torch.manual_seed(7)
+    pred, score = m.predict()
+    random.seed(7)
+    torch.manual_seed(7)
+    gen_kw = dict(points_per_batch=64, dense_pred=False, sel_pred_iou_thresh=0.0, sel_stability_score_thresh=0.0, box_nms_thresh=1.0,
+                  sel_output_layer=3, sel_multimask_output=True)
+    cfgf = {"emd": 0.0, "purity": 0.02, "coverage": 0.3, "score_filter": variant == "score_filter", "score": 0.9, "score_norm": 0.8}
+    merged, final, unfiltered, merged_from = omatch.mask_generation(
+        sam_sd, scfg.oracle_kw(), gen_kw, m.tar_img_np, want_pts, want_pts, pool_ref, oC, G, want_neg, use_neg=neg,
+        merge_prompt_types=neg, sample_range=(1, 3), max_iterations=6, alpha=0.8, beta=0.3, exp=0.5, score_filter_cfg=cfgf,
+        num_merging_mask=4)
+    assert pred.shape == merged.shape == (1, size, size)
+    assert m.get_unfiltered_generated_masks().shape == unfiltered.shape
+    assert float((m.get_unfiltered_generated_masks() != unfiltered).float().mean()) < 2e-3      # logits at the threshold
+    assert m.get_masks_to_merge().shape == merged_from.shape
+    assert float((pred.cpu() != merged).float().mean()) < 2e-3
+    assert abs(float(score) - final) < 1e-3
+
+
+def test_mars_on_matcher_proposals(pkg, cuda):
+    """The reference's whole workflow in one process: Matcher proposals -> MARS ranking; the ranking agrees with the
+    CPU oracle of the ranking path fed the same proposals."""
+    import random
+    from oracle import pipeline as opipe
+    cfg = tiny_config(pkg, nshot=1)
+    a = cfg["args"]
+    a.device, a.sam_size = "cuda:0", "tiny"
+    a.sample_range, a.max_sample_iterations = (1, 2), 6
+    sam_sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["tiny"], seed=5)
+    ep = pkg.synth.make_episode(43, size=cfg["size"], nshot=1, nprop=2)
+    M = importlib.import_module(pkg.__name__ + ".matcher.Matcher")
+    matcher = M.build_matcher_oss(a, state_dict=cfg["sds"]["dino"], sam_state_dict=sam_sd)
+    MARS = importlib.import_module(pkg.__name__ + ".mars.MARS")
+    mars = MARS.build_MARS_fss(a, state_dicts=cfg["sds"])
+    mars.mask_generator = M.MatcherProposals(matcher)
+    random.seed(3)
+    pred = mars.predict(ep["support_imgs"].to(cuda), ep["support_masks"].to(cuda), ep["query_img"].to(cuda))
+    props = matcher.get_unfiltered_generated_masks()
+    assert props.dim() == 3 and props.shape[0] >= 2 and set(props.unique().tolist()) <= {0.0, 1.0}
+    # distinct proposals only: exact duplicates tie in the min-max scaling of the ranking
+    _, first = np.unique(props.flatten(1).cpu().numpy(), axis=0, return_index=True)
+    keep = torch.as_tensor(np.sort(first))
+    mars.mask_generator = None
+    pred = mars.predict(ep["support_imgs"].to(cuda), ep["support_masks"].to(cuda), ep["query_img"].to(cuda), props[keep].to(cuda))
+    ref = opipe.mars_predict(cfg["oracle_models"], dict(ep, mask_proposals=props[keep].cpu()), cfg["tokens"])
+    got = mars.filtering_merging_component.scores()
+    assert maxdiff(got["score"], ref["scores"]["score"]) < TOL
+    assert int((pred.cpu() != ref["mask"]).sum()) == 0
