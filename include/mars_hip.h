@@ -168,6 +168,11 @@ int marship_rank(const double* emd, const float* aclip, const int32_t* cnt, cons
 /* merged = (sum of kept masks > 0) (FilteringMergingModule.py:219). */
 int marship_merge_masks(const float* masks, const uint8_t* keep, int N, int64_t HW, float* merged,
                         void* stream);
+/* Proposal hand-off (main_MARS.py:62 reads one [N, H, W] tensor per episode): the same masks as one bit per
+ * pixel, words[mask][j] bit i = masks[mask][32 j + i] > 0 with ceil(HW / 32) words per mask, and back to {0,1}
+ * floats.  No counterpart in the reference (it stores floats). */
+int marship_pack_masks(const float* masks, int n, int64_t HW, uint32_t* words, void* stream);
+int marship_unpack_masks(const uint32_t* words, int n, int64_t HW, float* masks, void* stream);
 /* Intersection / union areas (mars/utils/evaluation.py:11-39): counts[0..3] += {inter0, inter1,
  * union0, union1} over pixels whose ignore flag is 0. */
 int marship_iou_counts(const float* pred, const float* gt, const float* ignore, int64_t HW,

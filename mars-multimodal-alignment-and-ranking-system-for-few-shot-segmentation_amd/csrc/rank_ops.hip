@@ -615,3 +615,43 @@ extern "C" int marship_iou_counts(const float* pred, const float* gt, const floa
     MARS_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- bit-packed proposal cache ---------------------------------------------------------------
+// words[mask, j] bit i = masks[mask, 32 j + i] > 0.  A wave covers 64 consecutive pixels; its ballot is two words.
+__global__ __launch_bounds__(256) void pack_masks_kernel(const float* __restrict__ masks, int64_t HW, int64_t nwords,
+                                                         uint32_t* __restrict__ words) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float* m = masks + (int64_t)blockIdx.y * HW;
+    const unsigned long long b = __ballot(e < HW && m[e < HW ? e : 0] > 0.f);
+    if ((threadIdx.x & 63) == 0) {
+        const int64_t w = e >> 5;
+        uint32_t* o = words + (int64_t)blockIdx.y * nwords;
+        if (w < nwords) o[w] = (uint32_t)b;
+        if (w + 1 < nwords) o[w + 1] = (uint32_t)(b >> 32);
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_masks_kernel(const uint32_t* __restrict__ words, int64_t HW, int64_t nwords,
+                                                           float* __restrict__ masks) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= HW) return;
+    const uint32_t w = words[(int64_t)blockIdx.y * nwords + (e >> 5)];
+    masks[(int64_t)blockIdx.y * HW + e] = (w >> (e & 31)) & 1u ? 1.f : 0.f;
+}
+
+extern "C" int marship_pack_masks(const float* masks, int n, int64_t HW, uint32_t* words, void* stream) {
+    MARS_CHECK(masks && words && n > 0 && n <= 65535 && HW > 0, "pack_masks: bad arguments");
+    hipLaunchKernelGGL(pack_masks_kernel, dim3((unsigned)((HW + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, masks, HW,
+                       (HW + 31) / 32, words);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_unpack_masks(const uint32_t* words, int n, int64_t HW, float* masks, void* stream) {
+    MARS_CHECK(masks && words && n > 0 && n <= 65535 && HW > 0, "unpack_masks: bad arguments");
+    hipLaunchKernelGGL(unpack_masks_kernel, dim3((unsigned)((HW + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, words, HW,
+                       (HW + 31) / 32, masks);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}

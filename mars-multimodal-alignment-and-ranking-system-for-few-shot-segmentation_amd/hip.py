@@ -75,6 +75,8 @@ _SIGNATURES = {
     "marship_threshold_masks": [_P, _F, _P, _L, _P],
     "marshost_box_nms": [_P, _P, _I, _F, _P, _P],
     "marshost_lap": [_P, _L, _I, _I, _I, _P, _P],
+    "marship_pack_masks": [_P, _I, _L, _P, _P],
+    "marship_unpack_masks": [_P, _I, _L, _P, _P],
     "marship_cosine_table": [_P, _L, _I, _I, _P, _I, _F, _P, _P],
     "marship_layernorm_bwd": [_P, _P, _P, _L, _F, _I, _P, _P, _I, _I, _F, _P],
     "marship_quickgelu_bwd": [_P, _P, _P, _L, _P],

@@ -557,3 +557,22 @@ def lap_host(weights: torch.Tensor, maximize: bool = False):
     if rc < 0:
         hip.check(rc, "marshost_lap")
     return rows, cols
+
+
+def pack_masks(masks: torch.Tensor, words: torch.Tensor):
+    """masks f32 [n, ...] -> words int32 [n, ceil(HW / 32)], bit i of word j = pixel 32 j + i > 0."""
+    _dev(masks, words)
+    n = masks.shape[0]
+    HW = masks.numel() // n
+    _req(masks.is_contiguous() and masks.dtype == torch.float32, "pack_masks: masks must be contiguous f32")
+    _req(words.dtype == torch.int32 and words.is_contiguous() and words.numel() == n * ((HW + 31) // 32), "pack_masks: words")
+    hip.check(hip.lib().marship_pack_masks(ptr(masks), n, HW, ptr(words), stream()), "marship_pack_masks")
+
+
+def unpack_masks(words: torch.Tensor, masks: torch.Tensor):
+    _dev(masks, words)
+    n = masks.shape[0]
+    HW = masks.numel() // n
+    _req(masks.is_contiguous() and masks.dtype == torch.float32, "unpack_masks: masks must be contiguous f32")
+    _req(words.dtype == torch.int32 and words.is_contiguous() and words.numel() == n * ((HW + 31) // 32), "unpack_masks: words")
+    hip.check(hip.lib().marship_unpack_masks(ptr(words), n, HW, ptr(masks), stream()), "marship_unpack_masks")

@@ -1,0 +1,139 @@
+"""File formats and episode readers either side of the ranking path (host side; files are made by the test)."""
+import importlib
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def mods():
+    pkg = load_package(require_native=False)
+    return importlib.import_module(pkg.__name__ + ".io"), importlib.import_module(pkg.__name__ + ".data")
+
+
+@pytest.mark.parametrize("protocol", [0, 2, 4, 5])
+def test_plain_pickle_reader(mods, tmp_path, protocol):
+    pio, _ = mods
+    obj = {0: ["train2014/a.jpg", "train2014/b.jpg"], 4: [], 8: ["x"] * 300, "meta": (1, 2.5, None, True, b"raw", -2 ** 40),
+           "nested": {"s": {1, 2, 3}, "t": ((), [[]])}}
+    if protocol < 4:                 # older protocols spell sets and bytes as calls of globals: outside plain data
+        obj["meta"] = (1, 2.5, None, True, -2 ** 40)
+        obj["nested"] = {"t": ((), [[]])}
+    shared = ["same"]
+    obj["alias"] = [shared, shared]
+    path = tmp_path / "split.pkl"
+    path.write_bytes(pickle.dumps(obj, protocol=protocol))
+    got = pio.read_plain_pickle(str(path))
+    assert got == obj and got["alias"][0] is got["alias"][1]
+
+
+def test_plain_pickle_reader_refuses_objects(mods, tmp_path):
+    pio, _ = mods
+    for i, bad in enumerate([np.arange(3), torch.ones(2), os.path.join, complex(1, 2), {"k": np.float32(1)}]):
+        path = tmp_path / f"bad{i}.pkl"
+        path.write_bytes(pickle.dumps(bad))
+        with pytest.raises(ValueError):
+            pio.read_plain_pickle(str(path))
+    trunc = tmp_path / "trunc.pkl"
+    trunc.write_bytes(pickle.dumps({"a": [1, 2, 3]})[:-1])
+    with pytest.raises(ValueError):
+        pio.read_plain_pickle(str(trunc))
+
+
+def test_state_dict_reader(mods, tmp_path):
+    pio, _ = mods
+    sd = {"blocks.0.attn.qkv.weight": torch.randn(6, 2), "cls_token": torch.zeros(1, 1, 2)}
+    for name, obj in (("plain", sd), ("wrapped", {"model": sd, "epoch": 3}), ("ddp", {"state_dict": {"module." + k: v for k, v in sd.items()}})):
+        p = tmp_path / f"{name}.pth"
+        torch.save(obj, p)
+        got = pio.load_state_dict(str(p))
+        assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    p = tmp_path / "notsd.pth"
+    torch.save({"a": 1}, p)
+    with pytest.raises(ValueError):
+        pio.load_state_dict(str(p))
+    script = tmp_path / "scripted.pt"
+    torch.jit.save(torch.jit.script(torch.nn.Linear(2, 2)), str(script))
+    with pytest.raises(ValueError, match="TorchScript"):
+        pio.load_state_dict(str(script))
+
+
+def _write_images(root, names, rng, size=(40, 30)):
+    from PIL import Image
+    for n in names:
+        os.makedirs(os.path.dirname(os.path.join(root, n)), exist_ok=True)
+        Image.fromarray(rng.integers(0, 256, size=(size[1], size[0], 3), dtype=np.uint8)).save(os.path.join(root, n))
+
+
+def test_fss_reader(mods, tmp_path):
+    from PIL import Image
+    _, data = mods
+    rng = np.random.default_rng(0)
+    base = tmp_path / "FSS-1000"
+    cats = ["zebra_fish", "abacus"]
+    os.makedirs(base / "splits")
+    (base / "splits" / "test.txt").write_text("\n".join(cats) + "\n")
+    for c in cats:
+        _write_images(str(base / "data" / c), [f"{i}.jpg" for i in range(1, 11)], rng)
+        for i in range(1, 11):
+            m = (rng.random((30, 40)) > 0.5).astype(np.uint8) * 255
+            Image.fromarray(m).save(base / "data" / c / f"{i}.png")
+    data.FSSDataset.initialize(img_size=28, datapath=str(tmp_path), use_original_imgsize=False)
+    np.random.seed(0)
+    loader = data.FSSDataset.build_dataloader("fss", bsz=1, nworker=0, fold=0, split="test", shot=2)
+    assert len(loader.dataset) == 20 and loader.dataset.categories == sorted(cats)
+    b = next(iter(loader))
+    assert b["query_img"].shape == (1, 3, 28, 28) and b["support_imgs"].shape == (1, 2, 3, 28, 28)
+    assert b["query_mask"].shape == (1, 28, 28) and b["support_masks"].shape == (1, 2, 28, 28)
+    assert 0.0 <= float(b["query_img"].min()) and float(b["query_img"].max()) <= 1.0
+    assert set(b["query_mask"].unique().tolist()) <= {0.0, 1.0} and int(b["class_id"]) == 760      # 'abacus' sorts first
+    assert all(s[0] != b["query_name"][0] for s in b["support_names"])
+    # the image transform is Pillow's antialiased bilinear resize followed by /255
+    im = Image.open(b["query_name"][0]).convert("RGB").resize((28, 28), Image.BILINEAR)
+    assert torch.equal(b["query_img"][0], torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float() / 255)
+    with pytest.raises(NotImplementedError):
+        data.FSSDataset.build_dataloader("lvis", 1, 0, 0, "test")
+
+
+def test_coco_reader(mods, tmp_path):
+    from PIL import Image
+    _, data = mods
+    rng = np.random.default_rng(1)
+    base = tmp_path / "COCO2014"
+    fold, names_by_class = 1, {}
+    for c in [fold + 4 * v for v in range(20)]:
+        names = [f"val2014/img_{c}_{i}.jpg" for i in range(3)]
+        names_by_class[c] = names
+        _write_images(str(base), names, rng)
+        for n in names:
+            ann = rng.integers(0, 3, size=(30, 40)).astype(np.uint8) * (c + 1)      # 0, c+1, or 2(c+1) (another class)
+            os.makedirs(base / "annotations" / "val2014", exist_ok=True)
+            Image.fromarray(ann).save(str(base / "annotations" / n).replace(".jpg", ".png"))
+    os.makedirs(base / "splits" / "val")
+    (base / "splits" / "val" / f"fold{fold}.pkl").write_bytes(pickle.dumps(names_by_class))
+    data.FSSDataset.initialize(img_size=28, datapath=str(tmp_path), use_original_imgsize=False)
+    np.random.seed(3)
+    ds = data.FSSDataset.build_dataloader("coco", 1, 0, fold, "test", shot=1).dataset
+    assert len(ds) == 1000 and ds.class_ids == [fold + 4 * v for v in range(20)] and len(ds.img_metadata) == 60
+    b = ds[0]
+    c = int(b["class_id"])
+    assert c in ds.class_ids and b["query_name"] in names_by_class[c] and b["support_names"][0] != b["query_name"]
+    ann = np.asarray(Image.open(str(base / "annotations" / b["query_name"]).replace(".jpg", ".png")))
+    want = torch.nn.functional.interpolate(torch.from_numpy((ann == c + 1).astype(np.float32))[None, None], (28, 28), mode="nearest")[0, 0]
+    assert torch.equal(b["query_mask"], want) and b["org_query_imsize"] == (40, 30)
+
+
+def test_synthetic_dataset(mods):
+    _, data = mods
+    ds = data.DatasetSynthetic(3, 126, 2, 5, fold=2)
+    b = ds[1]
+    assert b["query_img"].shape == (3, 126, 126) and b["support_imgs"].shape == (2, 3, 126, 126)
+    assert b["mask_proposals"].shape == (5, 126, 126) and int(b["class_id"]) in ds.class_ids
+    assert torch.equal(ds[1]["query_img"], b["query_img"])

@@ -22,6 +22,7 @@ for g in "$@"; do
         pipeline) run pipeline tests/test_gpu_pipeline.py ;;
         shells) run shells tests/test_gpu_matcher_clip_pipeline.py ;;
         sam) run sam tests/test_gpu_sam.py ;;
+        io) run io tests/test_gpu_io_runner.py ;;
     esac
 done
 exit 0
