@@ -26,27 +26,44 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
 }
 
 // rel_h[bh, t, kh] = q[bh, t, :] . Rh[qh(t), kh, :],  rel_w[bh, t, kw] = q[bh, t, :] . Rw[qw(t), kw, :]
-// q is read from the packed qkv buffer: row (b*T + t), column head*hdp + d.  One wave per (bh, t).
+// q is read from the packed qkv buffer: row (b*T + t), column head*hdp + d.
+// A workgroup owns one table slice: blockIdx.z = 0 fixes the query row qh (the gw queries of that row
+// against Rh[qh]), blockIdx.z = 1 fixes the query column qw (the gh queries of that column against
+// Rw[qw]).  Queries and table slice are staged in LDS with rows padded by one float, then every
+// thread forms dot products of length hd in increasing d.
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_bias_kernel(const T* __restrict__ qkv, int64_t ld, int Tn, int H, int hd, int hdp,
                                                           int gw, int Hk, int Wk, const float* __restrict__ Rh,
                                                           const float* __restrict__ Rw, float* __restrict__ rel_h,
-                                                          float* __restrict__ rel_w, int64_t nrows) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // (b*H + head)*Tn + t
-    if (row >= nrows) return;
-    const int lane = threadIdx.x & 63;
-    const int t = (int)(row % Tn);
-    const int64_t bh = row / Tn;
+                                                          float* __restrict__ rel_w) {
+    extern __shared__ float shm[];
+    const int gh = Tn / gw;
+    const bool along_w = blockIdx.z == 1;
+    const int fixed = blockIdx.x;
+    if (fixed >= (along_w ? gw : gh)) return;
+    const int nr = along_w ? gh : gw, nk = along_w ? Wk : Hk, pitch = hd + 1;
+    const int64_t bh = blockIdx.y;
     const int head = (int)(bh % H);
     const int64_t b = bh / H;
-    const int qh = t / gw, qw = t % gw;
-    const T* q = qkv + (b * Tn + t) * ld + (int64_t)head * hdp;
-    for (int k = lane; k < Hk + Wk; k += 64) {
-        const float* r = k < Hk ? Rh + ((int64_t)qh * Hk + k) * hd : Rw + ((int64_t)qw * Wk + (k - Hk)) * hd;
+    float* qs = shm;
+    float* ts = shm + nr * pitch;
+    const float* table = along_w ? Rw + (int64_t)fixed * Wk * hd : Rh + (int64_t)fixed * Hk * hd;
+    for (int i = threadIdx.x; i < nr * hd; i += 256) {
+        const int r = i / hd, d = i % hd;
+        const int t = along_w ? r * gw + fixed : fixed * gw + r;
+        qs[r * pitch + d] = ld_as_f32<T>(qkv + (b * Tn + t) * ld + (int64_t)head * hdp + d);
+    }
+    for (int i = threadIdx.x; i < nk * hd; i += 256) ts[(i / hd) * pitch + i % hd] = table[i];
+    __syncthreads();
+    float* out = along_w ? rel_w : rel_h;
+    for (int o = threadIdx.x; o < nr * nk; o += 256) {
+        const int r = o / nk, k = o % nk;
+        const float* q = qs + r * pitch;
+        const float* tb = ts + k * pitch;
         float acc = 0.f;
-        for (int d = 0; d < hd; ++d) acc = fmaf(ld_as_f32<T>(q + d), r[d], acc);
-        if (k < Hk) rel_h[row * Hk + k] = acc;
-        else rel_w[row * Wk + (k - Hk)] = acc;
+        for (int d = 0; d < hd; ++d) acc = fmaf(q[d], tb[d], acc);
+        const int t = along_w ? r * gw + fixed : fixed * gw + r;
+        out[(bh * Tn + t) * nk + k] = acc;
     }
 }
 
@@ -79,6 +96,48 @@ __global__ __launch_bounds__(256) void softmax_bias_rows_kernel(const float* __r
     sum = block_reduce_sum(sum, sm);
     TOUT* pr = P + row * ldp;
     for (int k = threadIdx.x; k < ldp; k += 256) st_from_f32<TOUT>(pr + k, k < T ? rowbuf[k] / sum : 0.f);
+}
+
+// The same for rows of at most 256 entries (the 14 x 14 windows): one wave per row, the row in registers.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void softmax_bias_rows_small_kernel(const float* __restrict__ S, int64_t lds_, TOUT* __restrict__ P,
+                                                                      int64_t ldp, int T, const float* __restrict__ rel_h,
+                                                                      const float* __restrict__ rel_w, int Hk, int Wk, int64_t nrows) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const float* sr = S + row * lds_;
+    const float* rh = rel_h ? rel_h + row * Hk : nullptr;
+    const float* rw = rel_w ? rel_w + row * Wk : nullptr;
+    float v[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        v[j] = -INFINITY;
+        if (k < T) {
+            float x = sr[k];
+            if (rh) x = (x + rh[k / Wk]) + rw[k % Wk];
+            v[j] = x;
+        }
+        mx = fmaxf(mx, v[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = lane + 64 * j < T ? expf(v[j] - mx) : 0.f;
+        sum += v[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    TOUT* pr = P + row * ldp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        if (k < ldp) st_from_f32<TOUT>(pr + k, k < T ? v[j] / sum : 0.f);
+    }
 }
 
 // out[i, :] = [sin(2 pi ((2c - 1) . G)), cos(...)] for coordinate pairs c in [0,1]^2.  With labels:
@@ -182,10 +241,13 @@ extern "C" int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, in
     MARS_CHECK(qkv && Rh && Rw && rel_h && rel_w, "relpos_bias: null pointer");
     MARS_CHECK(B > 0 && T > 0 && H > 0 && hd > 0 && hdp >= hd && gw > 0 && T % gw == 0 && Hk > 0 && Wk > 0 && ld >= (int64_t)H * hdp,
                "relpos_bias: bad shape");
-    const int64_t nrows = (int64_t)B * H * T;
-    dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
-    if (dtype == 1) hipLaunchKernelGGL(relpos_bias_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, ld, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nrows);
-    else hipLaunchKernelGGL(relpos_bias_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)qkv, ld, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nrows);
+    const int gh = T / gw;
+    const int nmax = gh > gw ? gh : gw, kmax = Hk > Wk ? Hk : Wk;
+    const size_t shm = (size_t)(nmax + kmax) * (hd + 1) * sizeof(float);
+    MARS_CHECK(shm <= 64 * 1024 && (int64_t)B * H <= 65535, "relpos_bias: grid side %d, table side %d or head dim %d too large", nmax, kmax, hd);
+    dim3 grid((unsigned)nmax, (unsigned)(B * H), 2), block(256);
+    if (dtype == 1) hipLaunchKernelGGL(relpos_bias_kernel<__bf16>, grid, block, shm, (hipStream_t)stream, (const __bf16*)qkv, ld, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w);
+    else hipLaunchKernelGGL(relpos_bias_kernel<float>, grid, block, shm, (hipStream_t)stream, (const float*)qkv, ld, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w);
     MARS_LAUNCH_CHECK();
     return 0;
 }
@@ -197,6 +259,13 @@ extern "C" int marship_softmax_bias_rows(const float* S, int64_t lds_, void* P, 
     MARS_CHECK((rel_h == nullptr) == (rel_w == nullptr), "softmax_bias_rows: both bias terms or none");
     MARS_CHECK(!rel_h || (Hk > 0 && Wk > 0 && (int64_t)Hk * Wk == T), "softmax_bias_rows: Hk*Wk must equal T");
     MARS_CHECK(nrows < (1ll << 31), "softmax_bias_rows: too many rows");
+    if (T <= 256 && ldp <= 256) {
+        dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
+        if (out_dtype == 1) hipLaunchKernelGGL(softmax_bias_rows_small_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, S, lds_, (__bf16*)P, ldp, T, rel_h, rel_w, Hk, Wk, nrows);
+        else hipLaunchKernelGGL(softmax_bias_rows_small_kernel<float>, grid, block, 0, (hipStream_t)stream, S, lds_, (float*)P, ldp, T, rel_h, rel_w, Hk, Wk, nrows);
+        MARS_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((unsigned)nrows), block(256);
     const size_t shm = (size_t)T * sizeof(float);
     if (out_dtype == 1) hipLaunchKernelGGL(softmax_bias_rows_kernel<__bf16>, grid, block, shm, (hipStream_t)stream, S, lds_, (__bf16*)P, ldp, T, rel_h, rel_w, Hk, Wk);

@@ -533,9 +533,9 @@ def test_gather_rows_and_casts(pkg, cuda):
         assert float((o - _act(a, act)).abs().max()) < 1e-6
 
 
-def test_softmax_bias_rows_and_relpos(pkg, cuda):
+@pytest.mark.parametrize("B,H,gw,hd,hdp", [(2, 3, 5, 16, 64), (1, 2, 20, 80, 128), (3, 1, 14, 64, 64)])
+def test_softmax_bias_rows_and_relpos(pkg, cuda, B, H, gw, hd, hdp):
     ops = pkg.ops
-    B, H, gw, hd, hdp = 2, 3, 5, 16, 64
     T = gw * gw
     qkv = _rand((B * T, 3 * H * hdp), 44, cuda)
     Rh, Rw = _rand((gw, gw, hd), 45, cuda), _rand((gw, gw, hd), 46, cuda)
@@ -546,7 +546,7 @@ def test_softmax_bias_rows_and_relpos(pkg, cuda):
     ref_h = torch.einsum("bhwc,hkc->bhwk", q, Rh).reshape(-1, gw)
     ref_w = torch.einsum("bhwc,wkc->bhwk", q, Rw).reshape(-1, gw)
     assert float((rel_h - ref_h).abs().max()) < 1e-4 and float((rel_w - ref_w).abs().max()) < 1e-4
-    Tp = 64
+    Tp = -(-T // 64) * 64                                      # rows of 25 / 196 (one wave each) and of 400 entries
     S = _rand((B * H * T, Tp), 47, cuda)
     for dt in (torch.float32, torch.bfloat16):
         P = torch.full((B * H * T, Tp), 3.0, device=cuda, dtype=dt)

@@ -199,3 +199,26 @@ def test_episode_with_generated_proposals(pkg):
     assert maxdiff(got["score"], ref["scores"]["score"]) < 1e-4
     assert got["order"].tolist() == ref["scores"]["order"].tolist()
     assert int((pred.cpu() != ref["mask"]).sum()) == 0
+
+
+def test_bf16_run_agrees_with_fp32(pkg):
+    """bf16 GEMM operands cannot meet the fp32 tolerance; the run is judged on mask overlap and IoU-head agreement."""
+    sa = pkg.segment_anything
+    cfg = pkg.synth.SAM_ARCHS["tiny"]
+    sd = pkg.synth.sam_state_dict(cfg, seed=5)
+    img = GOLD["sam_tiny_image"]
+    pts = torch.as_tensor(GOLD["sam_tiny_points"]).float()[:, None, :].cuda()
+    lab = torch.ones(pts.shape[0], 1, dtype=torch.int32).cuda()
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        pred = sa.SamPredictor(sa.sam_model_registry["tiny"](state_dict=sd, device="cuda", dtype=dt))
+        pred.set_image(img)
+        out[dt] = pred.predict_torch(pts, lab, return_logits=True)
+    m32, i32, _ = out[torch.float32]
+    m16, i16, _ = out[torch.bfloat16]
+    assert float((i32 - i16).abs().max()) < 0.05
+    scale = float(m32.abs().max())
+    assert float((m32 - m16).abs().max()) < 0.05 * scale
+    a, b = m32 > 0, m16 > 0
+    inter, union = (a & b).flatten(1).sum(1).float(), (a | b).flatten(1).sum(1).float().clamp(min=1)
+    assert float((inter / union)[union > 50].min()) > 0.9
