@@ -1,0 +1,107 @@
+"""The benchmark configuration itself (DINOv2-L/14 @518, CLIP ViT-B/16, AlphaCLIP ViT-L/14@336, 64 proposals,
+bf16 towers, synthetic weights): the CPU oracle needs minutes per episode at this size, so the checks are
+properties that hold at any size - invariance under proposal order and under batch splitting, ranges,
+count identities, EMD against the exact solver on the same cost rows, fp32 / bf16 rank agreement."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full(pkg):
+    MARS = importlib.import_module(pkg.__name__ + ".mars.MARS")
+    sds = bench.state_dicts(pkg)
+    mars = MARS.build_MARS_fss(bench.build_args(torch.device("cuda:0"), torch.bfloat16), state_dicts=sds)
+    ep = pkg.synth.make_episode(1000 * bench.FOLD + 1, size=bench.SIZE, nshot=1, nprop=bench.NPROP, fold=bench.FOLD)
+    ep = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ep.items()}
+    return mars, ep, sds
+
+
+def _run(mars, ep, props):
+    pred = mars.predict(ep["support_imgs"], ep["support_masks"], ep["query_img"], props).clone()
+    sc = {k: v.clone() for k, v in mars.filtering_merging_component.scores().items()}
+    return pred, sc
+
+
+def test_order_of_proposals_does_not_matter(full):
+    mars, ep, _ = full
+    pred, sc = _run(mars, ep, ep["mask_proposals"])
+    perm = torch.randperm(bench.NPROP, generator=torch.Generator().manual_seed(0))
+    pred_p, sc_p = _run(mars, ep, ep["mask_proposals"][perm.cuda()].contiguous())
+    assert torch.equal(pred, pred_p)
+    for k in ("emd", "aclip", "cnt", "svv", "svt", "score"):
+        assert torch.equal(sc[k][perm], sc_p[k]), k                   # every per-proposal quantity moves with its proposal
+    assert set(pred.unique().tolist()) <= {0.0, 1.0}
+    # ranges: EMD score and cosine in [-1, 1] / [0, 1], scores finite, the order sorts the scores
+    assert float(sc["emd"].min()) >= 0.0 and float(sc["emd"].max()) <= 1.0 + 1e-9
+    assert float(sc["aclip"].abs().max()) <= 1.0 + 1e-3 and bool(torch.isfinite(sc["score"]).all())
+    ordered = sc["score"][sc["order"].long()]
+    assert bool((ordered[:-1] >= ordered[1:]).all())
+    # the merged mask is the union of the kept proposals
+    kept = ep["mask_proposals"][sc["keep"].bool().cuda()]
+    assert torch.equal(pred, (kept.sum(0) > 0).float())
+
+
+def test_batch_split_and_exact_emd(full, pkg):
+    mars, ep, _ = full
+    fmm = mars.filtering_merging_component
+    _run(mars, ep, ep["mask_proposals"])
+    feats_all = fmm.scores()["feats"].clone()
+    # AlphaCLIP features of a subset computed alone equal the rows of the full batch (row-wise kernels)
+    sub = fmm._compute_alphaclip_vis_feats(ep["query_img"][0], ep["mask_proposals"][8:13].contiguous()).cpu()[:5]
+    assert torch.equal(sub, feats_all[8:13])
+    # EMD of three proposals against the CPU exact solver on the same similarity rows
+    from oracle.emd import emd2_uniform
+    vva = mars.visual_visual_alignment_component
+    S = vva.similarity_matrix
+    C = ((1 - S) / 2).double().numpy()
+    G = vva.model_embedding_spatial_dimensions
+    sb = torch.empty(G * G, dtype=torch.uint8, device="cuda")
+    pkg.ops.pool_masks(ep["support_masks"][0].contiguous().float(), G, sb)
+    rows = sb.cpu().bool().numpy()
+    bits = torch.empty(3, G * G, dtype=torch.uint8, device="cuda")
+    pkg.ops.pool_masks(ep["mask_proposals"][[0, 17, 40]].contiguous(), G, bits)
+    got = fmm.scores()["emd"][[0, 17, 40]]
+    for j in range(3):
+        cols = bits[j].cpu().bool().numpy()
+        if not cols.any():
+            cols[:] = True
+        want = 1.0 - emd2_uniform(C[rows][:, cols])
+        assert abs(float(got[j]) - want) < 1e-6, (j, float(got[j]), want)
+
+
+def test_iou_counts_identity(full, pkg):
+    mars, ep, _ = full
+    Evaluator = importlib.import_module(pkg.__name__ + ".mars.utils.evaluation").Evaluator
+    Evaluator.initialize()
+    pred, _ = _run(mars, ep, ep["mask_proposals"])
+    ai, au = Evaluator.classify_prediction(pred[None], ep)
+    n = pred.numel()
+    assert float(ai.sum() + au.sum()) == float(2 * n)                 # |pred_k| + |gt_k| over both bins
+    gt = ep["query_mask"][0]
+    assert float(ai[1]) == float(((pred > 0) & (gt > 0)).sum()) and float(au[1]) == float(((pred > 0) | (gt > 0)).sum())
+
+
+def test_fp32_towers_rank_like_bf16(full, pkg):
+    """Reported, loosely gated: Kendall tau of the final scores between the bf16 and the fp32 configuration."""
+    mars, ep, sds = full
+    _, sc16 = _run(mars, ep, ep["mask_proposals"])
+    MARS = importlib.import_module(pkg.__name__ + ".mars.MARS")
+    m32 = MARS.build_MARS_fss(bench.build_args(torch.device("cuda:0"), torch.float32), state_dicts=sds)
+    _, sc32 = _run(m32, ep, ep["mask_proposals"])
+    assert float((sc16["emd"] - sc32["emd"]).abs().max()) < 2e-2
+    a, b = sc16["score"].double().numpy(), sc32["score"].double().numpy()
+    n = len(a)
+    conc = sum(np.sign(a[i] - a[j]) * np.sign(b[i] - b[j]) for i in range(n) for j in range(i + 1, n))
+    tau = conc / (n * (n - 1) / 2)
+    print(f"kendall tau bf16 vs fp32 final scores: {tau:.3f}")
+    assert tau > 0.8

@@ -23,6 +23,7 @@ for g in "$@"; do
         shells) run shells tests/test_gpu_matcher_clip_pipeline.py ;;
         sam) run sam tests/test_gpu_sam.py ;;
         io) run io tests/test_gpu_io_runner.py ;;
+        full) run full tests/test_gpu_fullsize.py ;;
     esac
 done
 exit 0
