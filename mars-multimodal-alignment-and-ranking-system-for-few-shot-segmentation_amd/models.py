@@ -155,6 +155,45 @@ class Tower:
         return P
 
 
+def _first_token_block(self, x: torch.Tensor, blk: Block) -> torch.Tensor:
+    """The block's output for token 0 of every sequence, [B, D] f32 (x is left as it is).  A tower whose head
+    reads only the class token needs nothing else from its last block: keys and values still come from every
+    token, but the query, the attention output, both residual adds and the MLP are formed for one row per
+    sequence (same arithmetic per row as ``block_forward``; the attention is the unfused form)."""
+    assert blk.ffn == "mlp"
+    B, T, D = x.shape
+    H, dtp, dev = self.H, self.dtype, self.device
+    w = self.ws(B, T, blk.hidden_alloc)
+    Tp = w["Tp"]
+    f = w.get("first")
+    if f is None:
+        f = w["first"] = dict(
+            q=torch.zeros(B, D, dtype=dtp, device=dev), S=torch.zeros(B * H, 1, Tp, dtype=torch.float32, device=dev),
+            P=torch.zeros(B * H, 1, Tp, dtype=dtp, device=dev), VT=torch.zeros(B * H, 64, Tp, dtype=dtp, device=dev),
+            ao=torch.zeros(B, D, dtype=dtp, device=dev), xn=torch.zeros(B, D, dtype=dtp, device=dev),
+            hid=torch.zeros(B, blk.hidden_alloc, dtype=dtp, device=dev))
+    x2 = x.view(B * T, D)
+    ops.layernorm(x2, blk.ln1.w, blk.ln1.b, w["xn"], blk.ln1.eps)
+    qkv = w["qkv"]
+    ops.linear(w["xn"], blk.qkv.w[D:], qkv[:, D:], bias=blk.qkv.b[D:])              # keys and values of every token
+    ops.linear(w["xn"].view(B, T, D)[:, 0], blk.qkv.w[:D], f["q"], bias=blk.qkv.b[:D])   # queries of token 0
+    ops.gemm(f["q"], qkv, f["S"], 1, T, 64, lda=D, ldb=3 * D, ldc=Tp, b_off=D, nb0=B, nb1=H, sA=(D, 64),
+             sB=(T * 3 * D, 64), sC=(H * Tp, Tp), alpha=0.125)
+    ops.softmax_bias_rows(f["S"], f["P"], B * H, T)
+    ops.transpose_raw(qkv, 2 * D, 3 * D, (T * 3 * D, 64), f["VT"], 0, Tp, (H * 64 * Tp, 64 * Tp), T, 64, B, H)
+    ops.gemm(f["P"], f["VT"], f["ao"], 1, 64, Tp, lda=Tp, ldb=Tp, ldc=D, nb0=B, nb1=H, sA=(H * Tp, Tp),
+             sB=(H * 64 * Tp, 64 * Tp), sC=(D, 64))
+    xc = x[:, 0, :].clone()
+    ops.linear(f["ao"], blk.proj.w, xc, bias=blk.proj.b, gamma=blk.ls1, residual=xc)
+    ops.layernorm(xc, blk.ln2.w, blk.ln2.b, f["xn"], blk.ln2.eps)
+    ops.linear(f["xn"], blk.fc1.w, f["hid"][:, : blk.fc1.N], bias=blk.fc1.b, act=blk.act)
+    ops.linear(f["hid"], blk.fc2.w, xc, bias=blk.fc2.b, gamma=blk.ls2, residual=xc)
+    return xc
+
+
+Tower.block_forward_first_token = _first_token_block
+
+
 def _make_block(sd: SD, names: dict, D: int, device, dtype, eps: float, act: int, ffn: str = "mlp") -> Block:
     b = Block()
     b.ln1 = Norm(sd, names["ln1"], device, eps)
@@ -497,6 +536,7 @@ class AlphaCLIP(_TextTower):
         self.ln_pre = Norm(sd, "visual.ln_pre", device, 1e-5)
         self.ln_post = Norm(sd, "visual.ln_post", device, 1e-5)
         self.vproj_t = Lin(sd["visual.proj"].t().contiguous(), None, torch.float32, device)  # [E, W]
+        self.first_token_last_block = os.environ.get("MARS_FULL_LAST_BLOCK", "0") != "1"
         self._bufs: Dict[int, dict] = {}
         self.input_resolution = cfg.image_resolution
 
@@ -543,9 +583,13 @@ class AlphaCLIP(_TextTower):
         ops.write_prefix_tokens(X, self.class_embedding, self.vpos[0], None)
         X2 = X.view(n * T, D)
         ops.layernorm(X2, self.ln_pre.w, self.ln_pre.b, X2, self.ln_pre.eps)
-        for blk in self.vtower.blocks:
+        for blk in self.vtower.blocks[:-1]:
             self.vtower.block_forward(X, blk)
-        cls_rows = X[:, 0, :]                                    # view with row stride T*D
+        if self.first_token_last_block:
+            cls_rows = self.vtower.block_forward_first_token(X, self.vtower.blocks[-1])   # only the class token is read below
+        else:
+            self.vtower.block_forward(X, self.vtower.blocks[-1])
+            cls_rows = X[:, 0, :]                                # view with row stride T*D
         ops.layernorm(cls_rows, self.ln_post.w, self.ln_post.b, b["cls"], self.ln_post.eps)
         ops.linear(b["cls"], self.vproj_t.w, b["feat"])
         return b["feat"]

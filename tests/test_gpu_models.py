@@ -138,3 +138,22 @@ def test_backbone_loader_seam(pkg, cuda):
     assert maxdiff(enc.forward_features(x)["x_prenorm"], G["dino_vit_tiny2_x_prenorm"]) < TOL
     with pytest.raises(AssertionError):
         BL.load_backbone("resnet101", "resnet101")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_alphaclip_first_token_last_block(pkg, cuda, dtype):
+    """The last AlphaCLIP block formed for the class token only gives the features of the full block."""
+    synth = pkg.synth
+    cfg = synth.CLIP_ARCHS["tiny/14"]
+    sd = synth.clip_state_dict(cfg, 3, alpha=True)
+    m = pkg.models.AlphaCLIP(cfg, sd, device=cuda, dtype=dtype)
+    g = torch.Generator().manual_seed(5)
+    R = cfg.image_resolution
+    img = torch.rand(1, 3, R, R, generator=g).to(cuda)
+    alpha = torch.randn(5, 1, R, R, generator=g).to(cuda)
+    m.first_token_last_block = True
+    a = m.visual(img, alpha).clone()
+    m.first_token_last_block = False
+    b = m.visual(img, alpha).clone()
+    tol = 2e-5 if dtype == torch.float32 else 0.05
+    assert float((a - b).abs().max()) < tol * max(1.0, float(b.abs().max()))
