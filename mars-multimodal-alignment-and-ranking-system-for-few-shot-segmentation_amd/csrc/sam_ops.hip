@@ -141,20 +141,21 @@ __global__ __launch_bounds__(256) void softmax_bias_rows_small_kernel(const floa
 }
 
 // out[i, :] = [sin(2 pi ((2c - 1) . G)), cos(...)] for coordinate pairs c in [0,1]^2.  With labels:
-// label -1 replaces the code by table row 0, labels 0 / 1 add table rows 1 / 2 (prompt_encoder.py:86-90).
+// label -1 replaces the code by table row 0, labels 0 / 1 add table rows 1 / 2 (prompt_encoder.py:86-90),
+// labels 2 / 3 (the two corners of a box, :93-101) add table rows 3 / 4.
 __global__ __launch_bounds__(256) void fourier_pe_kernel(const float* __restrict__ coords, const float* __restrict__ G, int F,
                                                          const int32_t* __restrict__ labels, const float* __restrict__ table,
                                                          float* __restrict__ out, int64_t ldo, int64_t n) {
     const int64_t i = blockIdx.x;
     if (i >= n) return;
     const float x = 2.f * coords[2 * i] - 1.f, y = 2.f * coords[2 * i + 1] - 1.f;
-    const int lab = labels ? labels[i] : 2;
+    const int lab = labels ? labels[i] : -2;          // no labels: the bare position code
     for (int f = threadIdx.x; f < F; f += 256) {
         float v = x * G[f] + y * G[F + f];          // row vector times the [2, F] matrix
         v = 2.f * 3.14159265358979323846f * v;
         float sv = sinf(v), cv = cosf(v);
         if (lab == -1) { sv = 0.f + table[f]; cv = 0.f + table[F + f]; }
-        else if (lab == 0 || lab == 1) { sv += table[(int64_t)(lab + 1) * 2 * F + f]; cv += table[(int64_t)(lab + 1) * 2 * F + F + f]; }
+        else if (lab >= 0 && lab <= 3) { sv += table[(int64_t)(lab + 1) * 2 * F + f]; cv += table[(int64_t)(lab + 1) * 2 * F + F + f]; }
         out[i * ldo + f] = sv;
         out[i * ldo + F + f] = cv;
     }

@@ -11,8 +11,7 @@ Host work: the two assignment problems (C++ shortest augmenting paths), the tran
 (C++ network simplex, threads), and the list handling of points and prompt combinations, which
 follows the reference's order of operations and its draws from ``random`` / ``torch`` generators so
 that a seeded run picks the same prompts.  The per-mask scoring loop of the reference is one pooling
-launch, one point-count launch and N transport problems.  Box prompts and the cascaded mask input are
-not built.
+launch, one point-count launch and N transport problems.  The cascaded mask input is not built.
 """
 from __future__ import annotations
 
@@ -311,10 +310,12 @@ class Matcher:
             pts, k = self._negatives_from_cost(C.cpu(), idx_mask)
             priors.append(pts)
             n_neg.append(k)
-        if self.use_box:
-            raise NotImplementedError("box prompts are not built")
+        box = None
+        if self.use_box:                                                  # bounding box of the matched points, lines 567-573
+            box = np.array([max(points[:, 0].min(), 0), max(points[:, 1].min(), 0),
+                            min(points[:, 0].max(), self.input_size[1] - 1), min(points[:, 1].max(), self.input_size[0] - 1)])
         self.sim_scores_after_backward_matching = sim_pos
-        return points, (priors if priors else discarded), None, S, C, n_points, n_neg
+        return points, (priors if priors else discarded), box, S, C, n_points, n_neg
 
     def clustering(self, points):
         k = min(self.num_centers, len(points))
@@ -340,7 +341,7 @@ class Matcher:
         else:
             samples, labels = self.rps.sample_points(points)
         recs = self.generator.generate(tar_img_np, select_point_coords=samples, select_point_labels=labels,
-                                       select_box=None, select_mask_input=None)
+                                       select_box=[box] if self.use_box else None, select_mask_input=None)
         if len(recs) == 0:
             raise RuntimeError("the mask generator returned no mask for the sampled prompts")
         tar_masks = torch.from_numpy(np.stack([r["segmentation"] for r in recs])).to(self.device)      # n x H x W bool

@@ -493,7 +493,8 @@ def fourier_pe(coords: torch.Tensor, G: torch.Tensor, out: torch.Tensor, labels:
     _req(out.numel() >= n * 2 * F_, "fourier_pe: out size")
     if labels is not None:
         _req(labels.dtype == torch.int32 and labels.numel() == n and table is not None and table.dtype == torch.float32
-             and table.is_contiguous() and table.numel() == 3 * 2 * F_, "fourier_pe: labels/table")
+             and table.is_contiguous() and table.numel() == 5 * 2 * F_, "fourier_pe: labels/table (5 rows: not-a-point, "
+             "negative, positive, box corner 0, box corner 1)")
     hip.check(hip.lib().marship_fourier_pe(ptr(coords), ptr(G), F_, ptr(labels), ptr(table), ptr(out), 2 * F_, n, stream()),
               "marship_fourier_pe")
 

@@ -106,15 +106,20 @@ class SamAutomaticMaskGenerator:
         self._keep_batch(masks, iou, low, [[p] for p in points.tolist()], self.pred_iou_thresh, self.stability_score_thresh,
                          self.stability_score_offset, keep_lists)
 
-    def _process_sel_batch(self, im_size, point_coords: np.ndarray, point_labels: np.ndarray, keep_lists: dict):
-        """One batch of prompts of k points each: point_coords [B, k, 2] in image pixels, point_labels [B, k]."""
+    def _process_sel_batch(self, im_size, point_coords: np.ndarray, point_labels: np.ndarray, keep_lists: dict, box=None):
+        """One batch of prompts of k points each: point_coords [B, k, 2] in image pixels, point_labels [B, k]; ``box``
+        (x0, y0, x1, y1 in image pixels) is added to every prompt of the batch."""
         pr, dev = self.predictor, self.predictor.device
         point_coords = np.asarray(point_coords)
         if point_coords.ndim == 2:
             point_coords, point_labels = point_coords[None], np.asarray(point_labels)[None]
         tp = torch.as_tensor(pr.transform.apply_coords(point_coords, im_size), dtype=torch.float32, device=dev)
         labels = torch.as_tensor(np.asarray(point_labels), dtype=torch.int32, device=dev)
-        masks, iou, low = pr.predict_torch(tp, labels, multimask_output=self.sel_multimask_output, return_logits=True)
+        boxes = None
+        if box is not None:
+            b = torch.as_tensor(pr.transform.apply_boxes(np.asarray(box, dtype=np.float64), im_size), dtype=torch.float32, device=dev)
+            boxes = b.expand(tp.shape[0], -1) if b.shape[0] == 1 else b
+        masks, iou, low = pr.predict_torch(tp, labels, boxes=boxes, multimask_output=self.sel_multimask_output, return_logits=True)
         masks, iou, low = self._pick_layers(self.sel_output_layer, masks, iou, low)
         self._keep_batch(masks, iou, low, point_coords.tolist(), self.sel_pred_iou_thresh, self.sel_stability_score_thresh,
                          self.sel_stability_score_offset, keep_lists)
@@ -122,8 +127,12 @@ class SamAutomaticMaskGenerator:
     # ------------------------------------------------------------------ lines 160-243, 295-383
     def _run(self, image: np.ndarray, select_point_coords=None, select_point_labels=None, select_box=None,
              select_mask_input=None) -> dict:
-        if select_box is not None or select_mask_input is not None:
-            raise NotImplementedError("box and mask prompts are not built; point prompts only")
+        if select_mask_input is not None:
+            raise NotImplementedError("mask prompts are not built")
+        if select_box is not None:
+            if not (isinstance(select_box, list) and len(select_box) == 1):
+                raise NotImplementedError("select_box is a list holding one box (automatic_mask_generator.py:336-341)")
+            select_box = select_box[0]
         oh, ow = image.shape[:2]
         self.predictor.set_image(image)
         lists = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
@@ -136,7 +145,7 @@ class SamAutomaticMaskGenerator:
             for coords, labels in zip(select_point_coords, select_point_labels):     # one array per prompt size
                 for b0 in range(0, len(coords), self.points_per_batch):
                     self._process_sel_batch((oh, ow), coords[b0:b0 + self.points_per_batch],
-                                            labels[b0:b0 + self.points_per_batch], lists)
+                                            labels[b0:b0 + self.points_per_batch], lists, box=select_box)
         self.predictor.reset_image()
         if not lists["iou"]:
             return dict(masks=torch.zeros(0, oh, ow, device=self.predictor.device), iou=torch.zeros(0), stab=torch.zeros(0),

@@ -254,7 +254,9 @@ class PromptEncoder:
         self.gauss = _dev_f32(sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"], dev)
         self.table = torch.cat([_dev_f32(sd["prompt_encoder.not_a_point_embed.weight"], dev),
                                 _dev_f32(sd["prompt_encoder.point_embeddings.0.weight"], dev),
-                                _dev_f32(sd["prompt_encoder.point_embeddings.1.weight"], dev)], dim=0).contiguous()
+                                _dev_f32(sd["prompt_encoder.point_embeddings.1.weight"], dev),
+                                _dev_f32(sd["prompt_encoder.point_embeddings.2.weight"], dev),
+                                _dev_f32(sd["prompt_encoder.point_embeddings.3.weight"], dev)], dim=0).contiguous()
         self.no_mask = _dev_f32(sd["prompt_encoder.no_mask_embed.weight"], dev).reshape(-1)
         # dense positional code of the embedding grid (:194-205), token-major [G*G, C]
         ys, xs = torch.meshgrid((torch.arange(G) + 0.5) / G, (torch.arange(G) + 0.5) / G, indexing="ij")
@@ -279,10 +281,31 @@ class PromptEncoder:
         ops.fourier_pe(c.contiguous(), self.gauss, out, labels=lab.contiguous().view(-1), table=self.table)
         return out
 
+    def embed_boxes(self, boxes: torch.Tensor) -> torch.Tensor:
+        """_embed_boxes (:93-101): boxes [B, 4] (x0, y0, x1, y1) in the input frame -> two corner tokens [B, 2, C]."""
+        b = boxes.to(self.device).float().reshape(-1, 2, 2) + 0.5
+        B = b.shape[0]
+        c = b / torch.tensor([self.input_image_size[1], self.input_image_size[0]], dtype=torch.float32, device=self.device)
+        lab = torch.tensor([2, 3], dtype=torch.int32, device=self.device).repeat(B)
+        out = torch.zeros(B, 2, self.embed_dim, dtype=torch.float32, device=self.device)
+        ops.fourier_pe(c.contiguous(), self.gauss, out, labels=lab, table=self.table)
+        return out
+
+    def embed_prompts(self, points=None, boxes=None) -> torch.Tensor:
+        """Sparse tokens of forward (:147-155): points (padded with a not-a-point token when there is no box), then box corners."""
+        parts = []
+        if points is not None:
+            parts.append(self.embed_points(torch.as_tensor(points[0]), torch.as_tensor(points[1]), pad=boxes is None))
+        if boxes is not None:
+            parts.append(self.embed_boxes(torch.as_tensor(boxes)))
+        if not parts:
+            raise NotImplementedError("a prompt needs points or a box (mask prompts are not built)")
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1).contiguous()
+
     def __call__(self, points=None, boxes=None, masks=None):
-        if boxes is not None or masks is not None or points is None:
-            raise NotImplementedError("this proposal path embeds point prompts only")
-        sparse = self.embed_points(points[0], points[1], pad=True)
+        if masks is not None:
+            raise NotImplementedError("mask prompts are not built")
+        sparse = self.embed_prompts(points, boxes)
         G = self.image_embedding_size[0]
         dense = self.no_mask.view(1, -1, 1, 1).expand(sparse.shape[0], -1, G, G)
         return sparse, dense

@@ -29,6 +29,10 @@ class ResizeLongestSide:
         coords[..., 1] = coords[..., 1] * (new_h / old_h)
         return coords
 
+    def apply_boxes(self, boxes: np.ndarray, original_size) -> np.ndarray:
+        """transforms.py:59-65: [B, 4] boxes as two corner points each."""
+        return self.apply_coords(np.asarray(boxes).reshape(-1, 2, 2), original_size).reshape(-1, 4)
+
 
 class SamPredictor:
     def __init__(self, sam_model: Sam):
@@ -76,13 +80,14 @@ class SamPredictor:
 
     def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output: bool = True,
                       return_logits: bool = False):
-        """predictor.py:177-251 for point prompts: coords [B, N, 2] in the model's input frame, labels [B, N]."""
+        """predictor.py:177-251 for point and box prompts: coords [B, N, 2] and boxes [B, 4] in the model's input
+        frame, labels [B, N]."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
-        if boxes is not None or mask_input is not None or point_coords is None:
-            raise NotImplementedError("point prompts only")
+        if mask_input is not None:
+            raise NotImplementedError("mask prompts are not built")
         m = self.model
-        sparse = m.prompt_encoder.embed_points(torch.as_tensor(point_coords), torch.as_tensor(point_labels), pad=True)
+        sparse = m.prompt_encoder.embed_prompts((point_coords, point_labels) if point_coords is not None else None, boxes)
         masks4, iou4 = m.mask_decoder.predict_masks(self.features_tokens, m.prompt_encoder.dense_pe_tokens, sparse, m.prompt_encoder.no_mask)
         sl = slice(1, None) if multimask_output else slice(0, 1)
         low, iou = masks4[:, sl].contiguous(), iou4[:, sl].contiguous()

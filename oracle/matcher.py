@@ -142,9 +142,15 @@ def negatives_from_cost(C: torch.Tensor, idxs_mask, g, patch, input_size):
     return _inds_to_points(fwd[1][order[:n]], g, patch, input_size), n
 
 
+def points_box(points: np.ndarray, input_size) -> np.ndarray:
+    """Lines 567-573: the box prompt is the bounding box of the matched points."""
+    return np.array([max(points[:, 0].min(), 0), max(points[:, 1].min(), 0),
+                     min(points[:, 0].max(), input_size[1] - 1), min(points[:, 1].max(), input_size[0] - 1)])
+
+
 def patch_level_matching(S: torch.Tensor, ref_masks_pool: torch.Tensor, g: int, patch: int, input_size,
                          neg_from_discarded: bool = False, neg_from_cost: bool = False):
-    """Lines 419-577 (no box).  S [ns*P, P] on the CPU.  Returns (points, negatives-or-discarded, C, n, n_neg)."""
+    """Lines 419-577 (the box is ``points_box``).  S [ns*P, P] on the CPU.  Returns (points, negatives-or-discarded, C, n, n_neg)."""
     from scipy.optimize import linear_sum_assignment
     C = (1 - S) / 2
     fg = ref_masks_pool.flatten().bool()
@@ -226,8 +232,8 @@ def sample_points(points, negative_points=None, sample_range=(4, 6), max_iterati
 
 def mask_generation(sam_sd, sam_kw: dict, gen_kw: dict, tar_img_np: np.ndarray, points, all_points, ref_masks_pool, C, g: int,
                     negative_points=None, *, use_neg: bool = False, merge_prompt_types: bool = False, sample_range=(4, 6),
-                    max_iterations: int = 30, alpha=1.0, beta=0.0, exp=0.0, score_filter_cfg=None, num_merging_mask=10):
-    """Lines 619-834 (no box, no cascaded mask input).  Returns (merged [1, H, W] float, score, unfiltered masks, merged-from)."""
+                    max_iterations: int = 30, alpha=1.0, beta=0.0, exp=0.0, score_filter_cfg=None, num_merging_mask=10, box=None):
+    """Lines 619-834 (no cascaded mask input).  Returns (merged [1, H, W] float, score, unfiltered masks, merged-from)."""
     from . import sam as osam
     cfg = {"emd": 0.0, "purity": 0.0, "coverage": 0.0, "score_filter": False, "score": 0.33, "score_norm": 0.1,
            "topk_scores_threshold": 0.0}
@@ -245,7 +251,8 @@ def mask_generation(sam_sd, sam_kw: dict, gen_kw: dict, tar_img_np: np.ndarray, 
             samples_list.extend(s); label_list.extend(l)
     else:
         samples_list, label_list = sample_points(points, None, sample_range, max_iterations)
-    recs = osam.generate(sam_sd, sam_kw, tar_img_np, select_point_coords=samples_list, select_point_labels=label_list, **gen_kw)
+    recs = osam.generate(sam_sd, sam_kw, tar_img_np, select_point_coords=samples_list, select_point_labels=label_list,
+                         select_box=[box] if box is not None else None, **gen_kw)
     tar_masks = np.stack([r["segmentation"] for r in recs])[:, None] > 0
     coords = [r["point_coords"] for r in recs]
     sc = matcher_scores(tar_masks, all_points, C, ref_masks_pool, g, alpha, beta, exp)

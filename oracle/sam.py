@@ -147,6 +147,18 @@ def embed_points(sd: SD, points: torch.Tensor, labels: torch.Tensor, input_image
     return e
 
 
+def embed_boxes(sd: SD, boxes: torch.Tensor, input_image_size) -> torch.Tensor:
+    """PromptEncoder._embed_boxes (:93-101): boxes [B,4] in the model's input frame -> [B,2,C]."""
+    boxes = boxes + 0.5
+    c = boxes.reshape(-1, 2, 2).clone()
+    c[:, :, 0] = c[:, :, 0] / input_image_size[1]
+    c[:, :, 1] = c[:, :, 1] / input_image_size[0]
+    e = _pe_encoding(sd, c.to(torch.float))
+    e[:, 0, :] += sd["prompt_encoder.point_embeddings.2.weight"]
+    e[:, 1, :] += sd["prompt_encoder.point_embeddings.3.weight"]
+    return e
+
+
 # ----------------------------------------------------------------------------------------
 # mask decoder (mask_decoder.py, transformer.py)
 # ----------------------------------------------------------------------------------------
@@ -270,10 +282,15 @@ def set_image(sd: SD, cfg: dict, image: np.ndarray):
     return dict(features=feats, input_size=tuple(t.shape[-2:]), original_size=tuple(image.shape[:2]))
 
 
-def predict_torch(sd: SD, cfg: dict, state: dict, point_coords: torch.Tensor, point_labels: torch.Tensor, multimask_output=True):
-    """SamPredictor.predict_torch (predictor.py:177-251) with return_logits=True."""
+def predict_torch(sd: SD, cfg: dict, state: dict, point_coords: torch.Tensor, point_labels: torch.Tensor, multimask_output=True,
+                  boxes: torch.Tensor = None):
+    """SamPredictor.predict_torch (predictor.py:177-251) with return_logits=True; prompt tokens as
+    PromptEncoder.forward builds them (:147-155): points (padded only when there is no box), then box corners."""
     g = cfg["img_size"] // cfg["patch"]
-    sparse = embed_points(sd, point_coords.float(), point_labels.float(), (cfg["img_size"], cfg["img_size"]))
+    size = (cfg["img_size"], cfg["img_size"])
+    sparse = embed_points(sd, point_coords.float(), point_labels.float(), size, pad=boxes is None)
+    if boxes is not None:
+        sparse = torch.cat([sparse, embed_boxes(sd, boxes.float(), size)], dim=1)
     dense = sd["prompt_encoder.no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(sparse.shape[0], -1, g, g)
     low, iou = mask_decoder(sd, state["features"], dense_pe(sd, (g, g)), sparse, dense, cfg, multimask_output)
     masks = postprocess_masks(low, cfg["img_size"], state["input_size"], state["original_size"])
@@ -336,7 +353,7 @@ def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32,
              select_point_coords=None, select_point_labels=None, sel_pred_iou_thresh: float = 0.88,
              sel_stability_score_thresh: float = 0.95, sel_stability_score_offset: float = 1.0,
              multimask_output: bool = True, sel_multimask_output: bool = True, output_layer: int = -1,
-             sel_output_layer: int = -1) -> List[dict]:
+             sel_output_layer: int = -1, select_box=None) -> List[dict]:
     """SamAutomaticMaskGenerator.generate with one crop layer: the dense point grid
     (automatic_mask_generator.py:160-243, 295-383, 385-453) and / or the caller's prompt batches
     (select_point_coords: list of [n, k, 2] arrays, one per prompt size; lines 332-365, 455-556);
@@ -352,9 +369,13 @@ def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32,
             return [t[:, layer - 3:] for t in ts]
         return list(ts)
 
-    def batch(coords, labels, plist, multi, layer, iou_thr, stab_thr, stab_off):
+    def batch(coords, labels, plist, multi, layer, iou_thr, stab_thr, stab_off, box=None):
         tp = torch.as_tensor(apply_coords(coords, (oh, ow), cfg["img_size"]))
-        masks, iou, low = predict_torch(sd, cfg, state, tp, torch.as_tensor(labels), multi)
+        bt = None
+        if box is not None:                        # transforms.py:59-65 and automatic_mask_generator.py:483-489
+            bt = torch.as_tensor(apply_coords(np.asarray(box, dtype=float).reshape(-1, 2, 2), (oh, ow), cfg["img_size"]).reshape(-1, 4))
+            bt = bt.expand(tp.shape[0], -1)
+        masks, iou, low = predict_torch(sd, cfg, state, tp, torch.as_tensor(labels), multi, boxes=bt)
         masks, iou, low = pick(layer, masks, iou, low)
         nm = masks.shape[1]
         masks, iou, low = masks.flatten(0, 1), iou.flatten(0, 1), low.flatten(0, 1)
@@ -380,7 +401,8 @@ def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32,
             for b0 in range(0, len(coords), points_per_batch):
                 c = coords[b0:b0 + points_per_batch]
                 batch(c, labels[b0:b0 + points_per_batch], c.tolist(), sel_multimask_output, sel_output_layer,
-                      sel_pred_iou_thresh, sel_stability_score_thresh, sel_stability_score_offset)
+                      sel_pred_iou_thresh, sel_stability_score_thresh, sel_stability_score_offset,
+                      box=select_box[0] if select_box is not None else None)
     points = recs.pop("points")
     cat = {k: torch.cat(v, dim=0) for k, v in recs.items()} if recs["iou"] else None
     if cat is None or len(cat["iou"]) == 0:

@@ -286,6 +286,24 @@ def golden_sam(out):
         check("low_res_masks", ref_low, o_low, tol=2e-5)
         check("iou_predictions", ref_iou, o_iou, tol=2e-5)
         check("masks (logits)", ref_masks, o_masks, tol=2e-5)
+        # box prompts, alone and together with two points (no padding token then)
+        boxes = torch.tensor([[5.0, 9.0, 60.0, 70.0], [20.5, 3.0, 90.0, 50.25], [0.0, 0.0, 30.0, 30.0]])
+        pts2 = pts[:3, None, :].repeat(1, 2, 1).float() + torch.tensor([[0.0, 0.0], [7.0, -3.0]])
+        lab2 = torch.tensor([[1, 0]] * 3, dtype=torch.int)
+        with torch.no_grad():
+            sp_b, de_b = model.prompt_encoder(points=None, boxes=boxes, masks=None)
+            sp_pb, _ = model.prompt_encoder(points=(pts2, lab2), boxes=boxes, masks=None)
+            low_pb, iou_pb = model.mask_decoder(image_embeddings=ref_feat, image_pe=ref_pe, sparse_prompt_embeddings=sp_pb,
+                                                dense_prompt_embeddings=de_b, multimask_output=True)
+        check("box embeddings", sp_b, osam.embed_boxes(sd, boxes, (cfg.img_size, cfg.img_size)))
+        _, o_iou_pb, o_low_pb = osam.predict_torch(sd, kw, state, pts2, lab2, boxes=boxes)
+        check("points + box low_res_masks", low_pb, o_low_pb, tol=2e-5)
+        check("points + box iou", iou_pb, o_iou_pb, tol=2e-5)
+        out[f"sam_{arch}_boxes"] = boxes.numpy()
+        out[f"sam_{arch}_box_points"] = pts2.numpy()
+        out[f"sam_{arch}_box_sparse"] = sp_b.numpy()
+        out[f"sam_{arch}_box_low_res"] = low_pb.numpy()
+        out[f"sam_{arch}_box_iou"] = iou_pb.numpy()
         # amg helpers
         m = ref_masks.flatten(0, 1)
         check("stability score", amg.calculate_stability_score(m, 0.0, 1.0), osam.stability_score(m, 0.0, 1.0))

@@ -119,7 +119,7 @@ def test_clip_pipeline_process_masks(pkg, cuda):
     assert gen.resets >= 1 and pipe.target_img is None
 
 
-@pytest.mark.parametrize("variant", ["plain", "negatives", "score_filter"])
+@pytest.mark.parametrize("variant", ["plain", "negatives", "score_filter", "box"])
 def test_matcher_predict_end_to_end(pkg, cuda, variant):
     """Matcher.predict (assignment matching, prompt sets, SAM prompt batches, metric filters, merge) against the
     oracle's restatement under equal seeds.  Parity unpinned except for the assignment step (scipy)."""
@@ -135,6 +135,7 @@ def test_matcher_predict_end_to_end(pkg, cuda, variant):
         a.use_negative_priors_from_discarded, a.use_negative_priors_from_cost, a.merge_prompt_types = True, True, True
     if variant == "score_filter":
         a.use_score_filter, a.deep_score_filter, a.deep_score_norm_filter = True, 0.9, 0.8
+    a.use_box = variant == "box"
     scfg = pkg.synth.SAM_ARCHS["tiny"]
     sam_sd = pkg.synth.sam_state_dict(scfg, seed=5)
     ep = pkg.synth.make_episode(41, size=cfg["size"], nshot=1, nprop=2)
@@ -150,8 +151,10 @@ def test_matcher_predict_end_to_end(pkg, cuda, variant):
     pool_ref = omatch.set_reference_pool(ep["support_masks"], 14)
     neg = variant == "negatives"
     want_pts, want_neg, oC, _, _ = omatch.patch_level_matching(oS, pool_ref, G, 14, (size, size), neg, neg)
-    got_pts, got_neg, _, _, _, _, _ = m.patch_level_matching()
+    got_pts, got_neg, got_box, _, _, _, _ = m.patch_level_matching()
     assert np.array_equal(got_pts, want_pts) and len(got_pts) >= 1
+    want_box = omatch.points_box(want_pts, (size, size)) if variant == "box" else None
+    assert (got_box is None) == (want_box is None) and (want_box is None or np.array_equal(got_box, want_box))
     if neg:
         assert len(got_neg) == len(want_neg) == 2
         for x, y in zip(got_neg, want_neg):
@@ -169,7 +172,7 @@ def test_matcher_predict_end_to_end(pkg, cuda, variant):
     merged, final, unfiltered, merged_from = omatch.mask_generation(
         sam_sd, scfg.oracle_kw(), gen_kw, m.tar_img_np, want_pts, want_pts, pool_ref, oC, G, want_neg, use_neg=neg,
         merge_prompt_types=neg, sample_range=(1, 3), max_iterations=6, alpha=0.8, beta=0.3, exp=0.5, score_filter_cfg=cfgf,
-        num_merging_mask=4)
+        num_merging_mask=4, box=want_box)
     assert pred.shape == merged.shape == (1, size, size)
     assert m.get_unfiltered_generated_masks().shape == unfiltered.shape
     assert float((m.get_unfiltered_generated_masks() != unfiltered).float().mean()) < 2e-3      # logits at the threshold

@@ -222,3 +222,28 @@ def test_bf16_run_agrees_with_fp32(pkg):
     a, b = m32 > 0, m16 > 0
     inter, union = (a & b).flatten(1).sum(1).float(), (a | b).flatten(1).sum(1).float().clamp(min=1)
     assert float((inter / union)[union > 50].min()) > 0.9
+
+
+def test_box_prompts_match_reference_vectors(setup, pkg):
+    arch, cfg, sd, sam, osam = setup
+    boxes = torch.as_tensor(GOLD[f"sam_{arch}_boxes"]).cuda()
+    sparse, _ = sam.prompt_encoder(points=None, boxes=boxes, masks=None)
+    assert maxdiff(sparse, GOLD[f"sam_{arch}_box_sparse"]) < 2e-5
+    pred = pkg.segment_anything.SamPredictor(sam)
+    pred.set_image(GOLD[f"sam_{arch}_image"], stored_features=torch.as_tensor(GOLD[f"sam_{arch}_features"]))
+    pts = torch.as_tensor(GOLD[f"sam_{arch}_box_points"]).cuda()
+    lab = torch.tensor([[1, 0]] * 3, dtype=torch.int32).cuda()
+    _, iou, low = pred.predict_torch(pts, lab, boxes=boxes, return_logits=True)
+    assert maxdiff(low, GOLD[f"sam_{arch}_box_low_res"]) < TOL and maxdiff(iou, GOLD[f"sam_{arch}_box_iou"]) < TOL
+    # box alone: two corner tokens and no padding token
+    _, iou_b, low_b = pred.predict_torch(None, None, boxes=boxes, return_logits=True)
+    state = dict(features=torch.as_tensor(GOLD[f"sam_{arch}_features"]), input_size=pred.input_size, original_size=pred.original_size)
+    G = cfg.img_size // cfg.patch_size
+    sp = osam.embed_boxes(sd, boxes.cpu(), (cfg.img_size, cfg.img_size))
+    dense = sd["prompt_encoder.no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(3, -1, G, G)
+    rlow, riou = osam.mask_decoder(sd, state["features"], osam.dense_pe(sd, (G, G)), sp, dense, cfg.oracle_kw(), True)
+    assert maxdiff(low_b, rlow) < TOL and maxdiff(iou_b, riou) < TOL
+    tr = pkg.segment_anything.predictor.ResizeLongestSide(cfg.img_size)
+    b = np.array([[3.0, 4.0, 50.0, 61.5]])
+    hw = GOLD[f"sam_{arch}_image"].shape[:2]
+    assert np.allclose(tr.apply_boxes(b, hw), osam.apply_coords(b.reshape(-1, 2, 2), hw, cfg.img_size).reshape(-1, 4))

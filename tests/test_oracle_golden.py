@@ -101,6 +101,11 @@ def test_sam_encoder_decoder_postprocess(arch):
     assert maxdiff(low, G[f"sam_{arch}_low_res"]) < 5e-5
     assert maxdiff(iou, G[f"sam_{arch}_iou"]) < 5e-5
     assert maxdiff(masks, G[f"sam_{arch}_masks"]) < 5e-5
+    # box prompts alone (corner tokens) and two points plus a box through the decoder
+    boxes = torch.as_tensor(G[f"sam_{arch}_boxes"])
+    assert maxdiff(osam.embed_boxes(sd, boxes, (cfg.img_size, cfg.img_size)), G[f"sam_{arch}_box_sparse"]) < 2e-5
+    _, iou_b, low_b = osam.predict_torch(sd, kw, state, torch.as_tensor(G[f"sam_{arch}_box_points"]), torch.tensor([[1, 0]] * 3), boxes=boxes)
+    assert maxdiff(low_b, G[f"sam_{arch}_box_low_res"]) < 5e-5 and maxdiff(iou_b, G[f"sam_{arch}_box_iou"]) < 5e-5
 
 
 def test_sam_generator_structure():
