@@ -222,6 +222,12 @@ int marship_act_cast(const float* in, void* out, int64_t n, int act, int out_dty
  * x0, y0, x1, y1 of (> thr)} (int32 x 6; the box of an empty mask is 0,0,0,0). */
 int marship_mask_stats(const float* masks, int n, int H, int W, float thr, float off, int32_t* out,
                        void* stream);
+/* Dense embedding of mask prompts (segment_anything/modeling/prompt_encoder.py:51-58, 102-105): masks f32
+ * [B, 1, 4G, 4G] -> out f32 [B, G*G, C] (token-major).  w1 [m4,1,2,2], w2 [m,m4,2,2], w3 [C,m] with their biases,
+ * g / h = LayerNorm2d weight / bias. */
+int marship_mask_embed(const float* masks, int B, int G, int m4, int m, int C, const float* w1, const float* b1,
+                       const float* g1, const float* h1, const float* w2, const float* b2, const float* g2,
+                       const float* h2, const float* w3, const float* b3, float eps, float* out, void* stream);
 /* out = in > thr ? 1 : 0 (automatic_mask_generator.py:440). */
 int marship_threshold_masks(const float* in, float thr, float* out, int64_t n, void* stream);
 /* Greedy box NMS for one category (torchvision batched_nms as called at automatic_mask_generator.py:370-376):

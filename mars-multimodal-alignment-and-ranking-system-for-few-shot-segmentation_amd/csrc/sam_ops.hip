@@ -161,6 +161,65 @@ __global__ __launch_bounds__(256) void fourier_pe_kernel(const float* __restrict
     }
 }
 
+// Dense embedding of a mask prompt (prompt_encoder.py:51-58, 102-105): conv 2x2 s2 (1 -> m4) + LayerNorm2d + GELU,
+// conv 2x2 s2 (m4 -> m) + LayerNorm2d + GELU, conv 1x1 (m -> C), fused per output pixel: one workgroup forms the
+// 4 x 4 input patch's four stage-1 pixels, the stage-2 pixel and the C output channels, token-major out[b, pixel, :].
+__global__ __launch_bounds__(256) void mask_embed_kernel(const float* __restrict__ masks, int G, int m4, int m, int C,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ g1, const float* __restrict__ h1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ g2, const float* __restrict__ h2,
+                                                         const float* __restrict__ w3, const float* __restrict__ b3,
+                                                         float eps, float* __restrict__ out) {
+    __shared__ float r1[256], a1[256], r2[256], a2[256];
+    const int pix = blockIdx.x, gy = pix / G, gx = pix % G, t = threadIdx.x;
+    const int64_t W = 4 * (int64_t)G;
+    const float* in = masks + (int64_t)blockIdx.y * W * W;
+    if (t < 4 * m4) {
+        const int pos = t / m4, ch = t % m4, py = pos >> 1, px = pos & 1;
+        const int64_t y0 = 2 * (2 * gy + py), x0 = 2 * (2 * gx + px);
+        float acc = b1[ch];
+        for (int ky = 0; ky < 2; ++ky)
+            for (int kx = 0; kx < 2; ++kx) acc = fmaf(in[(y0 + ky) * W + x0 + kx], w1[ch * 4 + ky * 2 + kx], acc);
+        r1[t] = acc;
+    }
+    __syncthreads();
+    if (t < 4 * m4) {
+        const int pos = t / m4, ch = t % m4;
+        float u = 0.f, v = 0.f;
+        for (int c = 0; c < m4; ++c) u += r1[pos * m4 + c];
+        u /= (float)m4;
+        for (int c = 0; c < m4; ++c) { const float d = r1[pos * m4 + c] - u; v += d * d; }
+        v /= (float)m4;
+        const float y = g1[ch] * ((r1[t] - u) / sqrtf(v + eps)) + h1[ch];
+        a1[t] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    }
+    __syncthreads();
+    if (t < m) {
+        float acc = b2[t];
+        for (int c = 0; c < m4; ++c)
+            for (int pos = 0; pos < 4; ++pos) acc = fmaf(a1[pos * m4 + c], w2[(t * m4 + c) * 4 + pos], acc);   // w2[co, c, py, px]
+        r2[t] = acc;
+    }
+    __syncthreads();
+    if (t < m) {
+        float u = 0.f, v = 0.f;
+        for (int c = 0; c < m; ++c) u += r2[c];
+        u /= (float)m;
+        for (int c = 0; c < m; ++c) { const float d = r2[c] - u; v += d * d; }
+        v /= (float)m;
+        const float y = g2[t] * ((r2[t] - u) / sqrtf(v + eps)) + h2[t];
+        a2[t] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    }
+    __syncthreads();
+    float* o = out + ((int64_t)blockIdx.y * G * G + pix) * C;
+    for (int co = t; co < C; co += 256) {
+        float acc = b3[co];
+        for (int c = 0; c < m; ++c) acc = fmaf(a2[c], w3[(int64_t)co * m + c], acc);
+        o[co] = acc;
+    }
+}
+
 // out[r, :] = a[r, :] + b[r % b_rows, :]  (b may be null), written in the output type
 template <typename TOUT>
 __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t b_rows,
@@ -280,6 +339,18 @@ extern "C" int marship_fourier_pe(const float* coords, const float* G, int F, co
     MARS_CHECK(coords && G && out && F > 0 && n > 0 && ldo >= 2 * F && n < (1ll << 31), "fourier_pe: bad arguments");
     MARS_CHECK(!labels || table, "fourier_pe: labels need the embedding table");
     hipLaunchKernelGGL(fourier_pe_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, coords, G, F, labels, table, out, ldo, n);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_mask_embed(const float* masks, int B, int G, int m4, int m, int C, const float* w1, const float* b1,
+                                  const float* g1, const float* h1, const float* w2, const float* b2, const float* g2,
+                                  const float* h2, const float* w3, const float* b3, float eps, float* out, void* stream) {
+    MARS_CHECK(masks && out && w1 && b1 && g1 && h1 && w2 && b2 && g2 && h2 && w3 && b3, "mask_embed: null pointer");
+    MARS_CHECK(B > 0 && B <= 65535 && G > 0 && G <= 1024 && m4 > 0 && 4 * m4 <= 256 && m > 0 && m <= 256 && C > 0,
+               "mask_embed: bad shape (B=%d G=%d m4=%d m=%d C=%d)", B, G, m4, m, C);
+    hipLaunchKernelGGL(mask_embed_kernel, dim3((unsigned)(G * G), (unsigned)B), dim3(256), 0, (hipStream_t)stream, masks, G, m4, m, C,
+                       w1, b1, g1, h1, w2, b2, g2, h2, w3, b3, eps, out);
     MARS_LAUNCH_CHECK();
     return 0;
 }

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "marship_fourier_pe": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "marship_add_cast": [_P, _P, _L, _P, _L, _I, _I, _P],
     "marship_act_cast": [_P, _P, _L, _I, _I, _P],
+    "marship_mask_embed": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P],
     "marship_mask_stats": [_P, _I, _I, _I, _F, _F, _P, _P],
     "marship_threshold_masks": [_P, _F, _P, _L, _P],
     "marshost_box_nms": [_P, _P, _I, _F, _P, _P],

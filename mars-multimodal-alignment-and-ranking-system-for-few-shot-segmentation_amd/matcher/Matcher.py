@@ -11,7 +11,7 @@ Host work: the two assignment problems (C++ shortest augmenting paths), the tran
 (C++ network simplex, threads), and the list handling of points and prompt combinations, which
 follows the reference's order of operations and its draws from ``random`` / ``torch`` generators so
 that a seeded run picks the same prompts.  The per-mask scoring loop of the reference is one pooling
-launch, one point-count launch and N transport problems.  The cascaded mask input is not built.
+launch, one point-count launch and N transport problems.
 """
 from __future__ import annotations
 
@@ -326,8 +326,6 @@ class Matcher:
 
     # ---------------------------------------------------------------- lines 619-834
     def mask_generation(self, tar_img_np, points, box, all_points, ref_masks_pool, C, negative_points=None, target_mask=None):
-        if target_mask is not None:
-            raise NotImplementedError("the cascaded mask input is not built")
         samples, labels = [], []
         if self.use_negative_priors_from_discarded or self.use_negative_priors_from_cost:
             for neg in negative_points:
@@ -341,7 +339,8 @@ class Matcher:
         else:
             samples, labels = self.rps.sample_points(points)
         recs = self.generator.generate(tar_img_np, select_point_coords=samples, select_point_labels=labels,
-                                       select_box=[box] if self.use_box else None, select_mask_input=None)
+                                       select_box=[box] if self.use_box else None,
+                                       select_mask_input=target_mask.cpu().numpy() if target_mask is not None else None)
         if len(recs) == 0:
             raise RuntimeError("the mask generator returned no mask for the sampled prompts")
         tar_masks = torch.from_numpy(np.stack([r["segmentation"] for r in recs])).to(self.device)      # n x H x W bool

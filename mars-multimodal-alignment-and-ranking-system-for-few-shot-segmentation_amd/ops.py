@@ -577,3 +577,18 @@ def unpack_masks(words: torch.Tensor, masks: torch.Tensor):
     _req(masks.is_contiguous() and masks.dtype == torch.float32, "unpack_masks: masks must be contiguous f32")
     _req(words.dtype == torch.int32 and words.is_contiguous() and words.numel() == n * ((HW + 31) // 32), "unpack_masks: words")
     hip.check(hip.lib().marship_unpack_masks(ptr(words), n, HW, ptr(masks), stream()), "marship_unpack_masks")
+
+
+def mask_embed(masks: torch.Tensor, G: int, params, eps: float, out: torch.Tensor):
+    """masks f32 [B, 1, 4G, 4G] -> out f32 [B, G*G, C]; params = (w1, b1, g1, h1, w2, b2, g2, h2, w3, b3), all f32 contiguous."""
+    _dev(masks, out, *params)
+    B = masks.shape[0]
+    w1, b1, g1, h1, w2, b2, g2, h2, w3, b3 = params
+    m4, m, C = w1.shape[0], w2.shape[0], w3.shape[0]
+    _req(masks.dtype == torch.float32 and masks.is_contiguous() and tuple(masks.shape[1:]) == (1, 4 * G, 4 * G), "mask_embed: masks must be f32 [B,1,4G,4G]")
+    _req(all(p.dtype == torch.float32 and p.is_contiguous() for p in params), "mask_embed: parameters must be contiguous f32")
+    _req(w1.numel() == m4 * 4 and b1.numel() == m4 and g1.numel() == m4 and h1.numel() == m4 and w2.numel() == m * m4 * 4
+         and b2.numel() == m and g2.numel() == m and h2.numel() == m and w3.numel() == C * m and b3.numel() == C, "mask_embed: parameter sizes")
+    _req(out.dtype == torch.float32 and out.is_contiguous() and out.numel() == B * G * G * C, "mask_embed: out must be f32 [B, G*G, C]")
+    hip.check(hip.lib().marship_mask_embed(ptr(masks), B, G, m4, m, C, *[ptr(p) for p in params], float(eps), ptr(out), stream()),
+              "marship_mask_embed")

@@ -106,7 +106,8 @@ class SamAutomaticMaskGenerator:
         self._keep_batch(masks, iou, low, [[p] for p in points.tolist()], self.pred_iou_thresh, self.stability_score_thresh,
                          self.stability_score_offset, keep_lists)
 
-    def _process_sel_batch(self, im_size, point_coords: np.ndarray, point_labels: np.ndarray, keep_lists: dict, box=None):
+    def _process_sel_batch(self, im_size, point_coords: np.ndarray, point_labels: np.ndarray, keep_lists: dict, box=None,
+                           mask_input=None):
         """One batch of prompts of k points each: point_coords [B, k, 2] in image pixels, point_labels [B, k]; ``box``
         (x0, y0, x1, y1 in image pixels) is added to every prompt of the batch."""
         pr, dev = self.predictor, self.predictor.device
@@ -119,7 +120,11 @@ class SamAutomaticMaskGenerator:
         if box is not None:
             b = torch.as_tensor(pr.transform.apply_boxes(np.asarray(box, dtype=np.float64), im_size), dtype=torch.float32, device=dev)
             boxes = b.expand(tp.shape[0], -1) if b.shape[0] == 1 else b
-        masks, iou, low = pr.predict_torch(tp, labels, boxes=boxes, multimask_output=self.sel_multimask_output, return_logits=True)
+        if mask_input is not None:                                # one low-resolution mask for every prompt (lines 490-495)
+            mask_input = torch.as_tensor(np.asarray(mask_input), dtype=torch.float32, device=dev)
+            mask_input = mask_input[None] if mask_input.dim() == 3 else mask_input
+        masks, iou, low = pr.predict_torch(tp, labels, boxes=boxes, mask_input=mask_input, multimask_output=self.sel_multimask_output,
+                                           return_logits=True)
         masks, iou, low = self._pick_layers(self.sel_output_layer, masks, iou, low)
         self._keep_batch(masks, iou, low, point_coords.tolist(), self.sel_pred_iou_thresh, self.sel_stability_score_thresh,
                          self.sel_stability_score_offset, keep_lists)
@@ -127,8 +132,6 @@ class SamAutomaticMaskGenerator:
     # ------------------------------------------------------------------ lines 160-243, 295-383
     def _run(self, image: np.ndarray, select_point_coords=None, select_point_labels=None, select_box=None,
              select_mask_input=None) -> dict:
-        if select_mask_input is not None:
-            raise NotImplementedError("mask prompts are not built")
         if select_box is not None:
             if not (isinstance(select_box, list) and len(select_box) == 1):
                 raise NotImplementedError("select_box is a list holding one box (automatic_mask_generator.py:336-341)")
@@ -145,7 +148,8 @@ class SamAutomaticMaskGenerator:
             for coords, labels in zip(select_point_coords, select_point_labels):     # one array per prompt size
                 for b0 in range(0, len(coords), self.points_per_batch):
                     self._process_sel_batch((oh, ow), coords[b0:b0 + self.points_per_batch],
-                                            labels[b0:b0 + self.points_per_batch], lists, box=select_box)
+                                            labels[b0:b0 + self.points_per_batch], lists, box=select_box,
+                                            mask_input=select_mask_input)
         self.predictor.reset_image()
         if not lists["iou"]:
             return dict(masks=torch.zeros(0, oh, ow, device=self.predictor.device), iou=torch.zeros(0), stab=torch.zeros(0),

@@ -258,6 +258,10 @@ class PromptEncoder:
                                 _dev_f32(sd["prompt_encoder.point_embeddings.2.weight"], dev),
                                 _dev_f32(sd["prompt_encoder.point_embeddings.3.weight"], dev)], dim=0).contiguous()
         self.no_mask = _dev_f32(sd["prompt_encoder.no_mask_embed.weight"], dev).reshape(-1)
+        md = "prompt_encoder.mask_downscaling"
+        self.mask_params = tuple(_dev_f32(sd[f"{md}.{i}.{n}"], dev) for i, n in
+                                 ((0, "weight"), (0, "bias"), (1, "weight"), (1, "bias"), (3, "weight"), (3, "bias"),
+                                  (4, "weight"), (4, "bias"), (6, "weight"), (6, "bias")))
         # dense positional code of the embedding grid (:194-205), token-major [G*G, C]
         ys, xs = torch.meshgrid((torch.arange(G) + 0.5) / G, (torch.arange(G) + 0.5) / G, indexing="ij")
         grid = torch.stack([xs, ys], dim=-1).reshape(-1, 2).float().to(dev).contiguous()
@@ -302,12 +306,21 @@ class PromptEncoder:
             raise NotImplementedError("a prompt needs points or a box (mask prompts are not built)")
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1).contiguous()
 
+    def embed_masks_tokens(self, masks: torch.Tensor) -> torch.Tensor:
+        """_embed_masks (:102-105): low-resolution mask logits [B, 1, 4G, 4G] -> dense embedding, token-major [B, G*G, C]."""
+        G = self.image_embedding_size[0]
+        m = masks.to(self.device).float().contiguous()
+        out = torch.empty(m.shape[0], G * G, self.embed_dim, dtype=torch.float32, device=self.device)
+        ops.mask_embed(m, G, self.mask_params, 1e-6, out)
+        return out
+
     def __call__(self, points=None, boxes=None, masks=None):
-        if masks is not None:
-            raise NotImplementedError("mask prompts are not built")
         sparse = self.embed_prompts(points, boxes)
         G = self.image_embedding_size[0]
-        dense = self.no_mask.view(1, -1, 1, 1).expand(sparse.shape[0], -1, G, G)
+        if masks is not None:
+            dense = self.embed_masks_tokens(masks).view(-1, G, G, self.embed_dim).permute(0, 3, 1, 2)
+        else:
+            dense = self.no_mask.view(1, -1, 1, 1).expand(sparse.shape[0], -1, G, G)
         return sparse, dense
 
 
@@ -380,9 +393,11 @@ class MaskDecoder:
         self._attn.run(q, 0, k, 0, v, 0, o, nb, A.H, Tq, Tk, A.hdp, 1.0 / math.sqrt(A.hd))
         ops.linear(o, A.o.w, out, bias=A.o.b, residual=residual)
 
-    def predict_masks(self, feats_tokens: torch.Tensor, dense_pe_tokens: torch.Tensor, sparse: torch.Tensor, no_mask: torch.Tensor):
-        """predict_masks (:112-149) for point prompts: feats_tokens [Ni, C] f32 (one image), sparse [B, Np, C].
-        Returns (masks [B, 4, 4G, 4G] f32 logits, iou [B, 4])."""
+    def predict_masks(self, feats_tokens: torch.Tensor, dense_pe_tokens: torch.Tensor, sparse: torch.Tensor, no_mask: torch.Tensor,
+                      dense_tokens: Optional[torch.Tensor] = None):
+        """predict_masks (:112-149): feats_tokens [Ni, C] f32 (one image), sparse [B, Np, C]; the dense prompt embedding is
+        the ``no_mask`` vector, or ``dense_tokens`` [B, Ni, C] for mask prompts.  Returns (masks [B, 4, 4G, 4G] f32 logits,
+        iou [B, 4])."""
         cfg, C, dev, dtp = self.cfg, self.C, self.device, self.dtype
         B, Np, _ = sparse.shape
         Ni = feats_tokens.shape[0]
@@ -395,10 +410,13 @@ class MaskDecoder:
         pe = tokens.clone()                                        # query_pe = the initial point embedding
         Q = self._buf("Q", (B * Nt, C), f32); Q.copy_(tokens.view(B * Nt, C))
         # src = image embedding + dense prompt embedding, one copy per prompt (:126-127)
-        src0 = self._buf("src0", (Ni, C), f32)
-        ops.add_cast(feats_tokens, no_mask.view(1, C), src0)
         Kf = self._buf("K", (B * Ni, C), f32)
-        Kf.view(B, Ni, C).copy_(src0)
+        if dense_tokens is None:
+            src0 = self._buf("src0", (Ni, C), f32)
+            ops.add_cast(feats_tokens, no_mask.view(1, C), src0)
+            Kf.view(B, Ni, C).copy_(src0)
+        else:
+            ops.add_cast(dense_tokens.reshape(B * Ni, C).contiguous(), feats_tokens.contiguous(), Kf)
         qd, kd, vd = self._buf("qd", (B * Nt, C)), self._buf("kd", (B * Ni, C)), self._buf("vd", (B * Ni, C))
         td = self._buf("td", (B * Nt, C))
         hid = self._buf("hid", (B * Nt, self.layers[0]["lin2"].Kp))      # as wide as the padded K of lin2; pads stay zero
@@ -491,12 +509,14 @@ class MaskDecoder:
         return masks.view(B, 4, 4 * G, 4 * G), iou
 
     def __call__(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output: bool):
-        """Reference signature (:71-110) for a [1, C, G, G] embedding and the no-mask dense embedding."""
+        """Reference signature (:71-110) for a [1, C, G, G] image embedding and [B, C, G, G] dense prompt embeddings."""
         C = self.C
         feats = image_embeddings.to(self.device).float().permute(0, 2, 3, 1).reshape(-1, C).contiguous()
         pe = image_pe.to(self.device).float().permute(0, 2, 3, 1).reshape(-1, C).contiguous()
-        no_mask = dense_prompt_embeddings[0, :, 0, 0].to(self.device).float().contiguous()
-        masks, iou = self.predict_masks(feats, pe, sparse_prompt_embeddings.to(self.device).float(), no_mask)
+        sparse = sparse_prompt_embeddings.to(self.device).float()
+        dense = dense_prompt_embeddings.to(self.device).float().expand(sparse.shape[0], -1, -1, -1)
+        dense_tokens = dense.permute(0, 2, 3, 1).reshape(sparse.shape[0], -1, C).contiguous()
+        masks, iou = self.predict_masks(feats, pe, sparse, None, dense_tokens=dense_tokens)
         sl = slice(1, None) if multimask_output else slice(0, 1)
         return masks[:, sl], iou[:, sl]
 

@@ -80,15 +80,18 @@ class SamPredictor:
 
     def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output: bool = True,
                       return_logits: bool = False):
-        """predictor.py:177-251 for point and box prompts: coords [B, N, 2] and boxes [B, 4] in the model's input
-        frame, labels [B, N]."""
+        """predictor.py:177-251: coords [B, N, 2] and boxes [B, 4] in the model's input frame, labels [B, N],
+        mask_input [B or 1, 1, 4G, 4G] low-resolution logits of an earlier prediction."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
-        if mask_input is not None:
-            raise NotImplementedError("mask prompts are not built")
         m = self.model
         sparse = m.prompt_encoder.embed_prompts((point_coords, point_labels) if point_coords is not None else None, boxes)
-        masks4, iou4 = m.mask_decoder.predict_masks(self.features_tokens, m.prompt_encoder.dense_pe_tokens, sparse, m.prompt_encoder.no_mask)
+        dense_tokens = None
+        if mask_input is not None:                                # low-resolution logits [B or 1, 1, 4G, 4G]
+            mi = torch.as_tensor(mask_input).to(self.device).float()
+            dense_tokens = m.prompt_encoder.embed_masks_tokens(mi.expand(sparse.shape[0], -1, -1, -1))
+        masks4, iou4 = m.mask_decoder.predict_masks(self.features_tokens, m.prompt_encoder.dense_pe_tokens, sparse,
+                                                    m.prompt_encoder.no_mask, dense_tokens=dense_tokens)
         sl = slice(1, None) if multimask_output else slice(0, 1)
         low, iou = masks4[:, sl].contiguous(), iou4[:, sl].contiguous()
         masks = m.postprocess_masks(low, self.input_size, self.original_size)

@@ -232,8 +232,9 @@ def sample_points(points, negative_points=None, sample_range=(4, 6), max_iterati
 
 def mask_generation(sam_sd, sam_kw: dict, gen_kw: dict, tar_img_np: np.ndarray, points, all_points, ref_masks_pool, C, g: int,
                     negative_points=None, *, use_neg: bool = False, merge_prompt_types: bool = False, sample_range=(4, 6),
-                    max_iterations: int = 30, alpha=1.0, beta=0.0, exp=0.0, score_filter_cfg=None, num_merging_mask=10, box=None):
-    """Lines 619-834 (no cascaded mask input).  Returns (merged [1, H, W] float, score, unfiltered masks, merged-from)."""
+                    max_iterations: int = 30, alpha=1.0, beta=0.0, exp=0.0, score_filter_cfg=None, num_merging_mask=10, box=None,
+                    target_mask=None):
+    """Lines 619-834.  Returns (merged [1, H, W] float, score, unfiltered masks, merged-from)."""
     from . import sam as osam
     cfg = {"emd": 0.0, "purity": 0.0, "coverage": 0.0, "score_filter": False, "score": 0.33, "score_norm": 0.1,
            "topk_scores_threshold": 0.0}
@@ -252,7 +253,8 @@ def mask_generation(sam_sd, sam_kw: dict, gen_kw: dict, tar_img_np: np.ndarray, 
     else:
         samples_list, label_list = sample_points(points, None, sample_range, max_iterations)
     recs = osam.generate(sam_sd, sam_kw, tar_img_np, select_point_coords=samples_list, select_point_labels=label_list,
-                         select_box=[box] if box is not None else None, **gen_kw)
+                         select_box=[box] if box is not None else None,
+                         select_mask_input=target_mask.cpu().numpy() if target_mask is not None else None, **gen_kw)
     tar_masks = np.stack([r["segmentation"] for r in recs])[:, None] > 0
     coords = [r["point_coords"] for r in recs]
     sc = matcher_scores(tar_masks, all_points, C, ref_masks_pool, g, alpha, beta, exp)

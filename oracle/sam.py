@@ -147,6 +147,16 @@ def embed_points(sd: SD, points: torch.Tensor, labels: torch.Tensor, input_image
     return e
 
 
+def embed_masks(sd: SD, masks: torch.Tensor) -> torch.Tensor:
+    """PromptEncoder._embed_masks (:102-105, mask_downscaling :51-58): [B,1,4G,4G] -> [B,C,G,G]."""
+    p = "prompt_encoder.mask_downscaling"
+    x = F.conv2d(masks.float(), sd[p + ".0.weight"], sd[p + ".0.bias"], stride=2)
+    x = F.gelu(_ln2d(x, sd, p + ".1"))
+    x = F.conv2d(x, sd[p + ".3.weight"], sd[p + ".3.bias"], stride=2)
+    x = F.gelu(_ln2d(x, sd, p + ".4"))
+    return F.conv2d(x, sd[p + ".6.weight"], sd[p + ".6.bias"])
+
+
 def embed_boxes(sd: SD, boxes: torch.Tensor, input_image_size) -> torch.Tensor:
     """PromptEncoder._embed_boxes (:93-101): boxes [B,4] in the model's input frame -> [B,2,C]."""
     boxes = boxes + 0.5
@@ -283,7 +293,7 @@ def set_image(sd: SD, cfg: dict, image: np.ndarray):
 
 
 def predict_torch(sd: SD, cfg: dict, state: dict, point_coords: torch.Tensor, point_labels: torch.Tensor, multimask_output=True,
-                  boxes: torch.Tensor = None):
+                  boxes: torch.Tensor = None, mask_input: torch.Tensor = None):
     """SamPredictor.predict_torch (predictor.py:177-251) with return_logits=True; prompt tokens as
     PromptEncoder.forward builds them (:147-155): points (padded only when there is no box), then box corners."""
     g = cfg["img_size"] // cfg["patch"]
@@ -291,7 +301,10 @@ def predict_torch(sd: SD, cfg: dict, state: dict, point_coords: torch.Tensor, po
     sparse = embed_points(sd, point_coords.float(), point_labels.float(), size, pad=boxes is None)
     if boxes is not None:
         sparse = torch.cat([sparse, embed_boxes(sd, boxes.float(), size)], dim=1)
-    dense = sd["prompt_encoder.no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(sparse.shape[0], -1, g, g)
+    if mask_input is not None:
+        dense = embed_masks(sd, mask_input.float().expand(sparse.shape[0], -1, -1, -1))
+    else:
+        dense = sd["prompt_encoder.no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(sparse.shape[0], -1, g, g)
     low, iou = mask_decoder(sd, state["features"], dense_pe(sd, (g, g)), sparse, dense, cfg, multimask_output)
     masks = postprocess_masks(low, cfg["img_size"], state["input_size"], state["original_size"])
     return masks, iou, low
@@ -353,7 +366,7 @@ def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32,
              select_point_coords=None, select_point_labels=None, sel_pred_iou_thresh: float = 0.88,
              sel_stability_score_thresh: float = 0.95, sel_stability_score_offset: float = 1.0,
              multimask_output: bool = True, sel_multimask_output: bool = True, output_layer: int = -1,
-             sel_output_layer: int = -1, select_box=None) -> List[dict]:
+             sel_output_layer: int = -1, select_box=None, select_mask_input=None) -> List[dict]:
     """SamAutomaticMaskGenerator.generate with one crop layer: the dense point grid
     (automatic_mask_generator.py:160-243, 295-383, 385-453) and / or the caller's prompt batches
     (select_point_coords: list of [n, k, 2] arrays, one per prompt size; lines 332-365, 455-556);
@@ -369,13 +382,17 @@ def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32,
             return [t[:, layer - 3:] for t in ts]
         return list(ts)
 
-    def batch(coords, labels, plist, multi, layer, iou_thr, stab_thr, stab_off, box=None):
+    def batch(coords, labels, plist, multi, layer, iou_thr, stab_thr, stab_off, box=None, mask_input=None):
         tp = torch.as_tensor(apply_coords(coords, (oh, ow), cfg["img_size"]))
         bt = None
         if box is not None:                        # transforms.py:59-65 and automatic_mask_generator.py:483-489
             bt = torch.as_tensor(apply_coords(np.asarray(box, dtype=float).reshape(-1, 2, 2), (oh, ow), cfg["img_size"]).reshape(-1, 4))
             bt = bt.expand(tp.shape[0], -1)
-        masks, iou, low = predict_torch(sd, cfg, state, tp, torch.as_tensor(labels), multi, boxes=bt)
+        mi = None
+        if mask_input is not None:
+            mi = torch.as_tensor(np.asarray(mask_input), dtype=torch.float32)
+            mi = mi[None] if mi.dim() == 3 else mi
+        masks, iou, low = predict_torch(sd, cfg, state, tp, torch.as_tensor(labels), multi, boxes=bt, mask_input=mi)
         masks, iou, low = pick(layer, masks, iou, low)
         nm = masks.shape[1]
         masks, iou, low = masks.flatten(0, 1), iou.flatten(0, 1), low.flatten(0, 1)
@@ -402,7 +419,7 @@ def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32,
                 c = coords[b0:b0 + points_per_batch]
                 batch(c, labels[b0:b0 + points_per_batch], c.tolist(), sel_multimask_output, sel_output_layer,
                       sel_pred_iou_thresh, sel_stability_score_thresh, sel_stability_score_offset,
-                      box=select_box[0] if select_box is not None else None)
+                      box=select_box[0] if select_box is not None else None, mask_input=select_mask_input)
     points = recs.pop("points")
     cat = {k: torch.cat(v, dim=0) for k, v in recs.items()} if recs["iou"] else None
     if cat is None or len(cat["iou"]) == 0:

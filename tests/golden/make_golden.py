@@ -304,6 +304,19 @@ def golden_sam(out):
         out[f"sam_{arch}_box_sparse"] = sp_b.numpy()
         out[f"sam_{arch}_box_low_res"] = low_pb.numpy()
         out[f"sam_{arch}_box_iou"] = iou_pb.numpy()
+        # a mask prompt (the low-resolution logits of the first prediction fed back) with two points
+        mask_in = ref_low[:3, :1]
+        with torch.no_grad():
+            sp_m, de_m = model.prompt_encoder(points=(pts2, lab2), boxes=None, masks=mask_in)
+            low_m, iou_m = model.mask_decoder(image_embeddings=ref_feat, image_pe=ref_pe, sparse_prompt_embeddings=sp_m,
+                                              dense_prompt_embeddings=de_m, multimask_output=True)
+        check("mask embedding", de_m, osam.embed_masks(sd, mask_in), tol=2e-5)
+        _, o_iou_m, o_low_m = osam.predict_torch(sd, kw, state, pts2, lab2, mask_input=mask_in)
+        check("points + mask low_res_masks", low_m, o_low_m, tol=2e-5)
+        check("points + mask iou", iou_m, o_iou_m, tol=2e-5)
+        out[f"sam_{arch}_mask_dense"] = de_m.numpy()
+        out[f"sam_{arch}_mask_low_res"] = low_m.numpy()
+        out[f"sam_{arch}_mask_iou"] = iou_m.numpy()
         # amg helpers
         m = ref_masks.flatten(0, 1)
         check("stability score", amg.calculate_stability_score(m, 0.0, 1.0), osam.stability_score(m, 0.0, 1.0))

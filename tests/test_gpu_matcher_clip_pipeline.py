@@ -119,7 +119,7 @@ def test_clip_pipeline_process_masks(pkg, cuda):
     assert gen.resets >= 1 and pipe.target_img is None
 
 
-@pytest.mark.parametrize("variant", ["plain", "negatives", "score_filter", "box"])
+@pytest.mark.parametrize("variant", ["plain", "negatives", "score_filter", "box", "cascade"])
 def test_matcher_predict_end_to_end(pkg, cuda, variant):
     """Matcher.predict (assignment matching, prompt sets, SAM prompt batches, metric filters, merge) against the
     oracle's restatement under equal seeds.  Parity unpinned except for the assignment step (scipy)."""
@@ -161,9 +161,14 @@ def test_matcher_predict_end_to_end(pkg, cuda, variant):
             assert (x is None and y is None) or np.array_equal(x, y)
     else:
         assert np.array_equal(got_neg, want_neg)
+    # the cascaded step of the reference: low-resolution logits of an earlier prediction as an extra prompt
+    target_mask = None
+    if variant == "cascade":
+        gs = 4 * (scfg.img_size // scfg.patch_size)
+        target_mask = torch.randn(1, gs, gs, generator=torch.Generator().manual_seed(2)) * 3
     random.seed(7)
     torch.manual_seed(7)
-    pred, score = m.predict()
+    pred, score = m.predict(target_mask=target_mask)
     random.seed(7)
     torch.manual_seed(7)
     gen_kw = dict(points_per_batch=64, dense_pred=False, sel_pred_iou_thresh=0.0, sel_stability_score_thresh=0.0, box_nms_thresh=1.0,
@@ -172,7 +177,7 @@ def test_matcher_predict_end_to_end(pkg, cuda, variant):
     merged, final, unfiltered, merged_from = omatch.mask_generation(
         sam_sd, scfg.oracle_kw(), gen_kw, m.tar_img_np, want_pts, want_pts, pool_ref, oC, G, want_neg, use_neg=neg,
         merge_prompt_types=neg, sample_range=(1, 3), max_iterations=6, alpha=0.8, beta=0.3, exp=0.5, score_filter_cfg=cfgf,
-        num_merging_mask=4, box=want_box)
+        num_merging_mask=4, box=want_box, target_mask=target_mask)
     assert pred.shape == merged.shape == (1, size, size)
     assert m.get_unfiltered_generated_masks().shape == unfiltered.shape
     assert float((m.get_unfiltered_generated_masks() != unfiltered).float().mean()) < 2e-3      # logits at the threshold

@@ -247,3 +247,25 @@ def test_box_prompts_match_reference_vectors(setup, pkg):
     b = np.array([[3.0, 4.0, 50.0, 61.5]])
     hw = GOLD[f"sam_{arch}_image"].shape[:2]
     assert np.allclose(tr.apply_boxes(b, hw), osam.apply_coords(b.reshape(-1, 2, 2), hw, cfg.img_size).reshape(-1, 4))
+
+
+def test_mask_prompts_match_reference_vectors(setup, pkg):
+    arch, cfg, sd, sam, osam = setup
+    G = cfg.img_size // cfg.patch_size
+    mask_in = torch.as_tensor(GOLD[f"sam_{arch}_low_res"])[:3, :1].cuda()
+    pts = torch.as_tensor(GOLD[f"sam_{arch}_box_points"]).cuda()
+    lab = torch.tensor([[1, 0]] * 3, dtype=torch.int32).cuda()
+    _, dense = sam.prompt_encoder(points=(pts, lab), boxes=None, masks=mask_in)
+    assert dense.shape == (3, cfg.out_chans, G, G) and maxdiff(dense, GOLD[f"sam_{arch}_mask_dense"]) < 2e-5
+    pred = pkg.segment_anything.SamPredictor(sam)
+    pred.set_image(GOLD[f"sam_{arch}_image"], stored_features=torch.as_tensor(GOLD[f"sam_{arch}_features"]))
+    _, iou, low = pred.predict_torch(pts, lab, mask_input=mask_in, return_logits=True)
+    assert maxdiff(low, GOLD[f"sam_{arch}_mask_low_res"]) < TOL and maxdiff(iou, GOLD[f"sam_{arch}_mask_iou"]) < TOL
+    # one mask for the whole batch, and the module-style decoder call with a dense embedding
+    _, iou1, low1 = pred.predict_torch(pts, lab, mask_input=mask_in[:1], return_logits=True)
+    assert maxdiff(low1[0], low[0]) < 1e-6
+    feats = torch.as_tensor(GOLD[f"sam_{arch}_features"]).cuda()
+    sparse, _ = sam.prompt_encoder(points=(pts, lab), boxes=None, masks=None)
+    lowm, ioum = sam.mask_decoder(image_embeddings=feats, image_pe=sam.prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=sparse,
+                                  dense_prompt_embeddings=dense, multimask_output=True)
+    assert maxdiff(lowm, GOLD[f"sam_{arch}_mask_low_res"]) < TOL and maxdiff(ioum, GOLD[f"sam_{arch}_mask_iou"]) < TOL

@@ -106,6 +106,11 @@ def test_sam_encoder_decoder_postprocess(arch):
     assert maxdiff(osam.embed_boxes(sd, boxes, (cfg.img_size, cfg.img_size)), G[f"sam_{arch}_box_sparse"]) < 2e-5
     _, iou_b, low_b = osam.predict_torch(sd, kw, state, torch.as_tensor(G[f"sam_{arch}_box_points"]), torch.tensor([[1, 0]] * 3), boxes=boxes)
     assert maxdiff(low_b, G[f"sam_{arch}_box_low_res"]) < 5e-5 and maxdiff(iou_b, G[f"sam_{arch}_box_iou"]) < 5e-5
+    # a mask prompt: the first prediction's low-resolution logits fed back with two points
+    mask_in = torch.as_tensor(G[f"sam_{arch}_low_res"])[:3, :1]
+    assert maxdiff(osam.embed_masks(sd, mask_in), G[f"sam_{arch}_mask_dense"]) < 2e-5
+    _, iou_m, low_m = osam.predict_torch(sd, kw, state, torch.as_tensor(G[f"sam_{arch}_box_points"]), torch.tensor([[1, 0]] * 3), mask_input=mask_in)
+    assert maxdiff(low_m, G[f"sam_{arch}_mask_low_res"]) < 5e-5 and maxdiff(iou_m, G[f"sam_{arch}_mask_iou"]) < 5e-5
 
 
 def test_sam_generator_structure():
