@@ -243,6 +243,8 @@ SAM_ARCHS = {
     # test-size models: a window that does not divide the token grid (padding), one global block
     "tiny": SamCfg(64, 3, 2, (1,), img_size=128, window_size=3, out_chans=64, dec_heads=2, dec_mlp_dim=128, iou_head_hidden=64),
     "tiny80": SamCfg(320, 2, 4, (1,), img_size=96, window_size=4, out_chans=64, dec_heads=4, dec_mlp_dim=96, iou_head_hidden=48),
+    # the real geometry (1024 px, 64 x 64 tokens, 14 x 14 windows padded to 70, 256 decoder channels) on a narrow, shallow tower
+    "geom": SamCfg(128, 2, 2, (1,), dec_mlp_dim=256),
 }
 
 

@@ -269,3 +269,24 @@ def test_mask_prompts_match_reference_vectors(setup, pkg):
     lowm, ioum = sam.mask_decoder(image_embeddings=feats, image_pe=sam.prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=sparse,
                                   dense_prompt_embeddings=dense, multimask_output=True)
     assert maxdiff(lowm, GOLD[f"sam_{arch}_mask_low_res"]) < TOL and maxdiff(ioum, GOLD[f"sam_{arch}_mask_iou"]) < TOL
+
+
+def test_real_geometry_against_oracle(pkg):
+    """1024-pixel input, 64 x 64 tokens, 14 x 14 windows (grid padded to 70), 256-channel decoder, 8 decoder heads:
+    the shapes of the released models on a narrow two-block tower the CPU oracle finishes in seconds."""
+    from oracle import sam as osam
+    sa = pkg.segment_anything
+    cfg = pkg.synth.SAM_ARCHS["geom"]
+    sd = pkg.synth.sam_state_dict(cfg, seed=9)
+    sam = sa.sam_model_registry["geom"](state_dict=sd, device="cuda")
+    img = (pkg.synth.rand(4, "geom_img", (300, 400, 3)) * 255).to(torch.uint8).numpy()
+    pred = sa.SamPredictor(sam)
+    pred.set_image(img)
+    state = osam.set_image(sd, cfg.oracle_kw(), img)
+    assert pred.input_size == state["input_size"] == (768, 1024)
+    assert maxdiff(pred.features, state["features"]) < TOL
+    pts = torch.tensor([[[100.0, 200.0]], [[512.0, 384.0]], [[900.5, 50.25]]])
+    lab = torch.ones(3, 1)
+    masks, iou, low = pred.predict_torch(pts.cuda(), lab.int().cuda(), return_logits=True)
+    rm, ri, rl = osam.predict_torch(sd, cfg.oracle_kw(), state, pts, lab)
+    assert maxdiff(low, rl) < 5 * TOL and maxdiff(iou, ri) < 5 * TOL and maxdiff(masks, rm) < 5 * TOL
