@@ -537,6 +537,8 @@ def box_nms_host(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float
     """Greedy NMS on host tensors; returns the kept indices (int64) by decreasing score."""
     b = boxes.detach().cpu().float().contiguous()
     s = scores.detach().cpu().float().contiguous()
+    if b.shape[0] == 0:
+        return torch.zeros(0, dtype=torch.int64)
     n = b.shape[0]
     keep = torch.zeros(max(n, 1), dtype=torch.int32)
     cnt = ctypes.c_int32(0)

@@ -17,28 +17,28 @@ import numpy as np
 import torch
 
 from .. import ops
+from .amg import (area_from_rle, build_all_layer_point_grids, build_point_grid, generate_crop_boxes, is_box_near_crop_edge,  # noqa: F401
+                  mask_to_rle)
 from .modeling import Sam
 from .predictor import SamPredictor
-
-
-def build_point_grid(n_per_side: int) -> np.ndarray:
-    """utils/amg.py:179-187."""
-    offset = 1 / (2 * n_per_side)
-    side = np.linspace(offset, 1 - offset, n_per_side)
-    return np.stack([np.tile(side[None, :], (n_per_side, 1)), np.tile(side[:, None], (1, n_per_side))], axis=-1).reshape(-1, 2)
 
 
 class SamAutomaticMaskGenerator:
     def __init__(self, model: Sam, points_per_side: Optional[int] = 32, points_per_batch: int = 64, pred_iou_thresh: float = 0.88,
                  sel_pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0,
                  sel_stability_score_thresh: float = 0.95, sel_stability_score_offset: float = 1.0, box_nms_thresh: float = 0.7,
-                 crop_n_layers: int = 0, point_grids: Optional[List[np.ndarray]] = None, min_mask_region_area: int = 0,
+                 crop_n_layers: int = 0, crop_nms_thresh: float = 0.7, crop_overlap_ratio: float = 512 / 1500,
+                 crop_n_points_downscale_factor: int = 1, point_grids: Optional[List[np.ndarray]] = None, min_mask_region_area: int = 0,
                  output_mode: str = "binary_mask", multimask_output: bool = True, sel_multimask_output: bool = True,
                  output_layer: int = -1, sel_output_layer: int = -1, dense_pred: bool = True, **unused):
         assert (points_per_side is None) != (point_grids is None), "Exactly one of points_per_side or point_grid must be provided."
-        if crop_n_layers != 0 or min_mask_region_area != 0 or output_mode != "binary_mask":
-            raise NotImplementedError("one crop layer, binary masks, no small-region post-processing")
-        self.point_grids = [build_point_grid(points_per_side)] if points_per_side is not None else point_grids
+        assert output_mode in ("binary_mask", "uncompressed_rle", "coco_rle"), f"Unknown output_mode {output_mode}."
+        if min_mask_region_area != 0 or output_mode == "coco_rle":
+            raise NotImplementedError("small-region post-processing needs opencv and coco_rle needs pycocotools; neither is built")
+        self.point_grids = (build_all_layer_point_grids(points_per_side, crop_n_layers, crop_n_points_downscale_factor)
+                            if points_per_side is not None else point_grids)
+        self.crop_n_layers, self.crop_nms_thresh, self.crop_overlap_ratio = crop_n_layers, crop_nms_thresh, crop_overlap_ratio
+        self.crop_n_points_downscale_factor, self.output_mode = crop_n_points_downscale_factor, output_mode
         self.predictor = SamPredictor(model)
         self.points_per_batch = points_per_batch
         self.pred_iou_thresh = pred_iou_thresh
@@ -129,7 +129,48 @@ class SamAutomaticMaskGenerator:
         self._keep_batch(masks, iou, low, point_coords.tolist(), self.sel_pred_iou_thresh, self.sel_stability_score_thresh,
                          self.sel_stability_score_offset, keep_lists)
 
-    # ------------------------------------------------------------------ lines 160-243, 295-383
+    # ------------------------------------------------------------------ lines 160-243, 245-293, 295-383
+    def _process_crop(self, image: np.ndarray, crop_box, layer: int, select_point_coords, select_point_labels, select_box,
+                      select_mask_input) -> Optional[dict]:
+        """One crop: embedding, dense grid and (on the whole image only) the caller's prompts, edge filter, NMS; boxes,
+        points and masks come back in the image frame."""
+        oh, ow = image.shape[:2]
+        x0, y0, x1, y1 = crop_box
+        crop = image[y0:y1, x0:x1, :]
+        ch, cw = crop.shape[:2]
+        self.predictor.set_image(crop)
+        lists = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
+        if self.dense_pred:
+            pts_all = self.point_grids[layer] * np.array([[cw, ch]], dtype=np.float64)
+            for b0 in range(0, len(pts_all), self.points_per_batch):
+                self._process_batch(pts_all[b0:b0 + self.points_per_batch], (ch, cw), lists)
+        if layer == 0 and select_point_coords is not None:
+            assert select_point_labels is not None, "select_point_labels should not be None !"
+            for coords, labels in zip(select_point_coords, select_point_labels):     # one array per prompt size
+                for b0 in range(0, len(coords), self.points_per_batch):
+                    self._process_sel_batch((ch, cw), coords[b0:b0 + self.points_per_batch],
+                                            labels[b0:b0 + self.points_per_batch], lists, box=select_box,
+                                            mask_input=select_mask_input)
+        self.predictor.reset_image()
+        if not lists["iou"]:
+            return None
+        points = lists.pop("points")
+        cat = {k: torch.cat(v, dim=0) for k, v in lists.items()}
+        ok = ~is_box_near_crop_edge(cat["boxes"], crop_box, [0, 0, ow, oh])           # lines 443-446
+        order = ops.box_nms_host(cat["boxes"][ok], cat["iou"][ok], self.box_nms_thresh)
+        keep = torch.nonzero(ok).flatten()[order]
+        if keep.numel() == 0:
+            return None
+        out = {k: v[keep.to(v.device)] for k, v in cat.items()}
+        out["points"] = [[[x + x0, y + y0] for x, y in points[i]] for i in keep.tolist()]
+        out["boxes"] = out["boxes"] + torch.tensor([[x0, y0, x0, y0]], dtype=out["boxes"].dtype)
+        if (ch, cw) != (oh, ow):                                                      # masks of a crop, zero outside it
+            full = torch.zeros(out["masks"].shape[0], oh, ow, dtype=out["masks"].dtype, device=out["masks"].device)
+            full[:, y0:y1, x0:x1] = out["masks"]
+            out["masks"] = full
+        out["crop_boxes"] = torch.tensor([list(crop_box)] * len(keep), dtype=torch.float32).reshape(-1, 4)
+        return out
+
     def _run(self, image: np.ndarray, select_point_coords=None, select_point_labels=None, select_box=None,
              select_mask_input=None) -> dict:
         if select_box is not None:
@@ -137,28 +178,21 @@ class SamAutomaticMaskGenerator:
                 raise NotImplementedError("select_box is a list holding one box (automatic_mask_generator.py:336-341)")
             select_box = select_box[0]
         oh, ow = image.shape[:2]
-        self.predictor.set_image(image)
-        lists = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
-        if self.dense_pred:
-            pts_all = self.point_grids[0] * np.array([[ow, oh]], dtype=np.float64)
-            for b0 in range(0, len(pts_all), self.points_per_batch):
-                self._process_batch(pts_all[b0:b0 + self.points_per_batch], (oh, ow), lists)
-        if select_point_coords is not None:
-            assert select_point_labels is not None, "select_point_labels should not be None !"
-            for coords, labels in zip(select_point_coords, select_point_labels):     # one array per prompt size
-                for b0 in range(0, len(coords), self.points_per_batch):
-                    self._process_sel_batch((oh, ow), coords[b0:b0 + self.points_per_batch],
-                                            labels[b0:b0 + self.points_per_batch], lists, box=select_box,
-                                            mask_input=select_mask_input)
-        self.predictor.reset_image()
-        if not lists["iou"]:
+        boxes, layers, _ = generate_crop_boxes((oh, ow), self.crop_n_layers, self.crop_overlap_ratio)
+        parts = [p for p in (self._process_crop(image, cb, ly, select_point_coords, select_point_labels, select_box, select_mask_input)
+                             for cb, ly in zip(boxes, layers)) if p is not None]
+        if not parts:
             return dict(masks=torch.zeros(0, oh, ow, device=self.predictor.device), iou=torch.zeros(0), stab=torch.zeros(0),
-                        boxes=torch.zeros(0, 4), points=[], low=None, size=(oh, ow))
-        points = lists.pop("points")
-        cat = {k: torch.cat(v, dim=0) for k, v in lists.items()}
-        keep = ops.box_nms_host(cat["boxes"], cat["iou"], self.box_nms_thresh)
-        out = {k: v[keep.to(v.device)] for k, v in cat.items()}
-        out["points"] = [points[i] for i in keep.tolist()]
+                        boxes=torch.zeros(0, 4), points=[], low=None, crop_boxes=torch.zeros(0, 4), size=(oh, ow))
+        out = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0] if k != "points"}
+        out["points"] = [pt for p in parts for pt in p["points"]]
+        if len(boxes) > 1:                                                            # duplicates between crops: the smaller crop wins
+            cb = out["crop_boxes"]
+            scores = 1 / ((cb[:, 2] - cb[:, 0]) * (cb[:, 3] - cb[:, 1]))
+            keep = ops.box_nms_host(out["boxes"], scores, self.crop_nms_thresh)
+            pts = out.pop("points")
+            out = {k: v[keep.to(v.device)] for k, v in out.items()}
+            out["points"] = [pts[i] for i in keep.tolist()]
         out["size"] = (oh, ow)
         return out
 
@@ -170,10 +204,12 @@ class SamAutomaticMaskGenerator:
         masks_h = r["masks"].cpu().numpy() > 0 if len(r["iou"]) else np.zeros((0, oh, ow), bool)
         for i in range(len(r["iou"])):
             x0, y0, x1, y1 = [float(v) for v in r["boxes"][i].tolist()]
-            recs.append({"segmentation": masks_h[i], "area": int(masks_h[i].sum()), "bbox": [x0, y0, x1 - x0, y1 - y0],
+            c0, c1, c2, c3 = [float(v) for v in r["crop_boxes"][i].tolist()]
+            seg = masks_h[i] if self.output_mode == "binary_mask" else mask_to_rle(masks_h[i])
+            recs.append({"segmentation": seg, "area": int(masks_h[i].sum()), "bbox": [x0, y0, x1 - x0, y1 - y0],
                          "predicted_iou": float(r["iou"][i]), "point_coords": r["points"][i],
                          "low_res_masks": r["low"][i].cpu().numpy(), "stability_score": float(r["stab"][i]),
-                         "crop_box": [0.0, 0.0, float(ow), float(oh)]})
+                         "crop_box": [c0, c1, c2 - c0, c3 - c1]})
         return recs
 
     def generate_proposals(self, query_image: torch.Tensor, n: int) -> torch.Tensor:

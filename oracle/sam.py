@@ -360,20 +360,88 @@ def box_nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tens
     return torch.as_tensor(np.asarray(keep, dtype=np.int64))
 
 
+def generate_crop_boxes(im_size, n_layers: int, overlap_ratio: float):
+    """utils/amg.py:200-238."""
+    import math
+    from itertools import product
+    crop_boxes, layer_idxs = [], []
+    im_h, im_w = im_size
+    short_side = min(im_h, im_w)
+    crop_boxes.append([0, 0, im_w, im_h])
+    layer_idxs.append(0)
+
+    def crop_len(orig_len, n_crops, overlap):
+        return int(math.ceil((overlap * (n_crops - 1) + orig_len) / n_crops))
+
+    for i_layer in range(n_layers):
+        n_crops_per_side = 2 ** (i_layer + 1)
+        overlap = int(overlap_ratio * short_side * (2 / n_crops_per_side))
+        crop_w = crop_len(im_w, n_crops_per_side, overlap)
+        crop_h = crop_len(im_h, n_crops_per_side, overlap)
+        crop_box_x0 = [int((crop_w - overlap) * i) for i in range(n_crops_per_side)]
+        crop_box_y0 = [int((crop_h - overlap) * i) for i in range(n_crops_per_side)]
+        for x0, y0 in product(crop_box_x0, crop_box_y0):
+            crop_boxes.append([x0, y0, min(x0 + crop_w, im_w), min(y0 + crop_h, im_h)])
+            layer_idxs.append(i_layer + 1)
+    return crop_boxes, layer_idxs
+
+
+def is_box_near_crop_edge(boxes: torch.Tensor, crop_box, orig_box, atol: float = 20.0) -> torch.Tensor:
+    """utils/amg.py:78-88."""
+    crop_box_torch = torch.as_tensor(crop_box, dtype=torch.float)
+    orig_box_torch = torch.as_tensor(orig_box, dtype=torch.float)
+    x0, y0 = crop_box[0], crop_box[1]
+    boxes = (boxes + torch.tensor([[x0, y0, x0, y0]])).float()
+    near_crop_edge = torch.isclose(boxes, crop_box_torch[None, :], atol=atol, rtol=0)
+    near_image_edge = torch.isclose(boxes, orig_box_torch[None, :], atol=atol, rtol=0)
+    return torch.any(torch.logical_and(near_crop_edge, ~near_image_edge), dim=1)
+
+
+def mask_to_rle(tensor: torch.Tensor) -> List[dict]:
+    """utils/amg.py:107-135 ([b, h, w] bool -> uncompressed column-major run lengths)."""
+    b, h, w = tensor.shape
+    tensor = tensor.permute(0, 2, 1).flatten(1)
+    diff = tensor[:, 1:] ^ tensor[:, :-1]
+    change_indices = diff.nonzero()
+    out = []
+    for i in range(b):
+        cur = change_indices[change_indices[:, 0] == i, 1]
+        cur = torch.cat([torch.tensor([0], dtype=cur.dtype), cur + 1, torch.tensor([h * w], dtype=cur.dtype)])
+        btw = cur[1:] - cur[:-1]
+        counts = [] if tensor[i, 0] == 0 else [0]
+        counts.extend(btw.tolist())
+        out.append({"size": [h, w], "counts": counts})
+    return out
+
+
+def rle_to_mask(rle: dict) -> np.ndarray:
+    """utils/amg.py:138-149."""
+    h, w = rle["size"]
+    mask = np.empty(h * w, dtype=bool)
+    idx, parity = 0, False
+    for count in rle["counts"]:
+        mask[idx: idx + count] = parity
+        idx += count
+        parity ^= True
+    return mask.reshape(w, h).transpose()
+
+
 def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32, points_per_batch: int = 64,
              pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0,
              box_nms_thresh: float = 0.7, mask_threshold: float = 0.0, dense_pred: bool = True,
              select_point_coords=None, select_point_labels=None, sel_pred_iou_thresh: float = 0.88,
              sel_stability_score_thresh: float = 0.95, sel_stability_score_offset: float = 1.0,
              multimask_output: bool = True, sel_multimask_output: bool = True, output_layer: int = -1,
-             sel_output_layer: int = -1, select_box=None, select_mask_input=None) -> List[dict]:
-    """SamAutomaticMaskGenerator.generate with one crop layer: the dense point grid
-    (automatic_mask_generator.py:160-243, 295-383, 385-453) and / or the caller's prompt batches
-    (select_point_coords: list of [n, k, 2] arrays, one per prompt size; lines 332-365, 455-556);
-    binary-mask output."""
+             sel_output_layer: int = -1, select_box=None, select_mask_input=None, crop_n_layers: int = 0,
+             crop_nms_thresh: float = 0.7, crop_overlap_ratio: float = 512 / 1500, crop_n_points_downscale_factor: int = 1,
+             output_mode: str = "binary_mask") -> List[dict]:
+    """SamAutomaticMaskGenerator.generate (automatic_mask_generator.py:160-243): crops (:245-293), per crop the dense
+    point grid (:385-453) and, on the whole image, the caller's prompt batches (select_point_coords: list of
+    [n, k, 2] arrays, one per prompt size; :332-365, 455-556), the crop-edge filter and NMS (:369-383); binary-mask
+    or uncompressed-RLE output."""
     oh, ow = image.shape[:2]
-    state = set_image(sd, cfg, image)
-    recs = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
+    crop_boxes, layer_idxs = generate_crop_boxes((oh, ow), crop_n_layers, crop_overlap_ratio)
+    grids = [build_point_grid(int(points_per_side / (crop_n_points_downscale_factor ** i))) for i in range(crop_n_layers + 1)]
 
     def pick(layer, *ts):
         if sel_multimask_output and layer in (0, 1, 2):
@@ -382,54 +450,82 @@ def generate(sd: SD, cfg: dict, image: np.ndarray, *, points_per_side: int = 32,
             return [t[:, layer - 3:] for t in ts]
         return list(ts)
 
-    def batch(coords, labels, plist, multi, layer, iou_thr, stab_thr, stab_off, box=None, mask_input=None):
-        tp = torch.as_tensor(apply_coords(coords, (oh, ow), cfg["img_size"]))
-        bt = None
-        if box is not None:                        # transforms.py:59-65 and automatic_mask_generator.py:483-489
-            bt = torch.as_tensor(apply_coords(np.asarray(box, dtype=float).reshape(-1, 2, 2), (oh, ow), cfg["img_size"]).reshape(-1, 4))
-            bt = bt.expand(tp.shape[0], -1)
-        mi = None
-        if mask_input is not None:
-            mi = torch.as_tensor(np.asarray(mask_input), dtype=torch.float32)
-            mi = mi[None] if mi.dim() == 3 else mi
-        masks, iou, low = predict_torch(sd, cfg, state, tp, torch.as_tensor(labels), multi, boxes=bt, mask_input=mi)
-        masks, iou, low = pick(layer, masks, iou, low)
-        nm = masks.shape[1]
-        masks, iou, low = masks.flatten(0, 1), iou.flatten(0, 1), low.flatten(0, 1)
-        points = [plist[i // nm] for i in range(masks.shape[0])]
-        keep = iou > iou_thr if iou_thr > 0.0 else torch.ones_like(iou, dtype=torch.bool)
-        stab = stability_score(masks, mask_threshold, stab_off)
-        if stab_thr > 0.0:
-            keep = keep & (stab >= stab_thr)
-        idx = torch.nonzero(keep).flatten().tolist()
-        bin_ = masks[idx] > mask_threshold
-        recs["masks"].append(bin_); recs["iou"].append(iou[idx]); recs["stab"].append(stab[idx]); recs["low"].append(low[idx])
-        recs["boxes"].append(mask_to_box(bin_)); recs["points"].extend(points[i] for i in idx)
+    allc = dict(masks=[], iou=[], stab=[], boxes=[], low=[], crop=[])
+    all_points = []
+    for crop_box, layer_idx in zip(crop_boxes, layer_idxs):
+        x0, y0, x1, y1 = crop_box
+        crop = image[y0:y1, x0:x1, :]
+        ch, cw = crop.shape[:2]
+        state = set_image(sd, cfg, crop)
+        recs = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
 
-    if dense_pred:
-        pts_all = build_point_grid(points_per_side) * np.array([[ow, oh]], dtype=np.float64)
-        for b0 in range(0, len(pts_all), points_per_batch):
-            pts = pts_all[b0:b0 + points_per_batch]
-            batch(pts[:, None, :], np.ones((len(pts), 1), dtype=np.int64), [[p] for p in pts.tolist()], multimask_output,
-                  output_layer, pred_iou_thresh, stability_score_thresh, stability_score_offset)
-    if select_point_coords is not None:
-        for coords, labels in zip(select_point_coords, select_point_labels):
-            coords, labels = np.asarray(coords), np.asarray(labels)
-            for b0 in range(0, len(coords), points_per_batch):
-                c = coords[b0:b0 + points_per_batch]
-                batch(c, labels[b0:b0 + points_per_batch], c.tolist(), sel_multimask_output, sel_output_layer,
-                      sel_pred_iou_thresh, sel_stability_score_thresh, sel_stability_score_offset,
-                      box=select_box[0] if select_box is not None else None, mask_input=select_mask_input)
-    points = recs.pop("points")
-    cat = {k: torch.cat(v, dim=0) for k, v in recs.items()} if recs["iou"] else None
-    if cat is None or len(cat["iou"]) == 0:
+        def batch(coords, labels, plist, multi, layer, iou_thr, stab_thr, stab_off, box=None, mask_input=None):
+            tp = torch.as_tensor(apply_coords(coords, (ch, cw), cfg["img_size"]))
+            bt = None
+            if box is not None:                        # transforms.py:59-65 and automatic_mask_generator.py:483-489
+                bt = torch.as_tensor(apply_coords(np.asarray(box, dtype=float).reshape(-1, 2, 2), (ch, cw), cfg["img_size"]).reshape(-1, 4))
+                bt = bt.expand(tp.shape[0], -1)
+            mi = None
+            if mask_input is not None:
+                mi = torch.as_tensor(np.asarray(mask_input), dtype=torch.float32)
+                mi = mi[None] if mi.dim() == 3 else mi
+            masks, iou, low = predict_torch(sd, cfg, state, tp, torch.as_tensor(labels), multi, boxes=bt, mask_input=mi)
+            masks, iou, low = pick(layer, masks, iou, low)
+            nm = masks.shape[1]
+            masks, iou, low = masks.flatten(0, 1), iou.flatten(0, 1), low.flatten(0, 1)
+            points = [plist[i // nm] for i in range(masks.shape[0])]
+            keep = iou > iou_thr if iou_thr > 0.0 else torch.ones_like(iou, dtype=torch.bool)
+            stab = stability_score(masks, mask_threshold, stab_off)
+            if stab_thr > 0.0:
+                keep = keep & (stab >= stab_thr)
+            bin_ = masks > mask_threshold
+            boxes = mask_to_box(bin_).float()
+            keep = keep & ~is_box_near_crop_edge(boxes, crop_box, [0, 0, ow, oh])
+            idx = torch.nonzero(keep).flatten().tolist()
+            recs["masks"].append(bin_[idx]); recs["iou"].append(iou[idx]); recs["stab"].append(stab[idx]); recs["low"].append(low[idx])
+            recs["boxes"].append(boxes[idx]); recs["points"].extend(points[i] for i in idx)
+
+        if dense_pred:
+            pts_all = grids[layer_idx] * np.array([[cw, ch]], dtype=np.float64)
+            for b0 in range(0, len(pts_all), points_per_batch):
+                pts = pts_all[b0:b0 + points_per_batch]
+                batch(pts[:, None, :], np.ones((len(pts), 1), dtype=np.int64), [[p] for p in pts.tolist()], multimask_output,
+                      output_layer, pred_iou_thresh, stability_score_thresh, stability_score_offset)
+        if layer_idx == 0 and select_point_coords is not None:
+            for coords, labels in zip(select_point_coords, select_point_labels):
+                coords, labels = np.asarray(coords), np.asarray(labels)
+                for b0 in range(0, len(coords), points_per_batch):
+                    c = coords[b0:b0 + points_per_batch]
+                    batch(c, labels[b0:b0 + points_per_batch], c.tolist(), sel_multimask_output, sel_output_layer,
+                          sel_pred_iou_thresh, sel_stability_score_thresh, sel_stability_score_offset,
+                          box=select_box[0] if select_box is not None else None, mask_input=select_mask_input)
+        if not recs["iou"]:
+            continue
+        points = recs.pop("points")
+        cat = {k: torch.cat(v, dim=0) for k, v in recs.items()}
+        if len(cat["iou"]) == 0:
+            continue
+        keep = box_nms(cat["boxes"], cat["iou"], box_nms_thresh).tolist()
+        masks = torch.nn.functional.pad(cat["masks"][keep], (x0, ow - x1, y0, oh - y1), value=0)       # uncrop_masks, amg.py:262-272
+        allc["masks"].append(masks); allc["iou"].append(cat["iou"][keep]); allc["stab"].append(cat["stab"][keep])
+        allc["low"].append(cat["low"][keep])
+        allc["boxes"].append(cat["boxes"][keep] + torch.tensor([[x0, y0, x0, y0]], dtype=torch.float))
+        allc["crop"].append(torch.tensor([crop_box] * len(keep), dtype=torch.float).reshape(-1, 4))
+        all_points.extend([[px + x0, py + y0] for px, py in points[i]] for i in keep)
+    if not allc["iou"]:
         return []
-    keep = box_nms(cat["boxes"].float(), cat["iou"], box_nms_thresh)
+    cat = {k: torch.cat(v, dim=0) for k, v in allc.items()}
+    order = list(range(len(cat["iou"])))
+    if len(crop_boxes) > 1:
+        area = (cat["crop"][:, 2] - cat["crop"][:, 0]) * (cat["crop"][:, 3] - cat["crop"][:, 1])
+        order = box_nms(cat["boxes"], 1 / area, crop_nms_thresh).tolist()
     out = []
-    for i in keep.tolist():
+    for i in order:
         m = cat["masks"][i].numpy()
         x0, y0, x1, y1 = cat["boxes"][i].tolist()
-        out.append(dict(segmentation=m, area=int(m.sum()), bbox=[x0, y0, x1 - x0, y1 - y0], predicted_iou=float(cat["iou"][i]),
-                        point_coords=points[i], low_res_masks=cat["low"][i].numpy(),
-                        stability_score=float(cat["stab"][i]), crop_box=[0, 0, ow, oh]))
+        c0, c1, c2, c3 = cat["crop"][i].tolist()
+        seg = m if output_mode == "binary_mask" else mask_to_rle(cat["masks"][i][None])[0]
+        out.append(dict(segmentation=seg, area=int(m.sum()), bbox=[x0, y0, x1 - x0, y1 - y0], predicted_iou=float(cat["iou"][i]),
+                        point_coords=all_points[i], low_res_masks=cat["low"][i].numpy(),
+                        stability_score=float(cat["stab"][i]), crop_box=[c0, c1, c2 - c0, c3 - c1]))
     return out

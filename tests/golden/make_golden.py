@@ -322,6 +322,20 @@ def golden_sam(out):
         check("stability score", amg.calculate_stability_score(m, 0.0, 1.0), osam.stability_score(m, 0.0, 1.0))
         check("mask boxes", amg.batched_mask_to_box(m > 0), osam.mask_to_box(m > 0))
         check("point grid", amg.build_point_grid(5), osam.build_point_grid(5))
+        for size, layers, ratio in (((oh, ow), 2, 512 / 1500), ((480, 640), 1, 0.25), ((333, 77), 3, 0.4)):
+            rb, rl, _ = amg.generate_crop_boxes(size, layers, ratio)
+            ob, ol = osam.generate_crop_boxes(size, layers, ratio)
+            assert rb == ob and rl == ol, (size, layers)
+        bx = torch.tensor([[0, 0, 30, 30], [25, 3, 60, 40], [5, 28, 20, 62], [40, 40, 50, 50]], dtype=torch.float)
+        for cb in ([10, 20, 73, 84], [0, 0, 63, 64]):
+            assert torch.equal(amg.is_box_near_crop_edge(bx, cb, [0, 0, ow, oh]), osam.is_box_near_crop_edge(bx, cb, [0, 0, ow, oh]))
+        rles = amg.mask_to_rle_pytorch(m[:4] > 0)
+        assert rles == osam.mask_to_rle(m[:4] > 0)
+        assert all(np.array_equal(amg.rle_to_mask(r), osam.rle_to_mask(r)) and np.array_equal(osam.rle_to_mask(r), (m[i] > 0).numpy())
+                   for i, r in enumerate(rles))
+        print("  crop boxes / crop-edge filter / run-length codes: equal to utils.amg")
+        out[f"sam_{arch}_crop_boxes"] = np.asarray(amg.generate_crop_boxes((oh, ow), 2, 512 / 1500)[0], dtype=np.int64)
+        out[f"sam_{arch}_rle0_counts"] = np.asarray(rles[0]["counts"], dtype=np.int64)
         out[f"sam_{arch}_image"] = img
         out[f"sam_{arch}_features"] = ref_feat.numpy()
         out[f"sam_{arch}_points"] = pts.numpy()

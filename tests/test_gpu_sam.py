@@ -290,3 +290,31 @@ def test_real_geometry_against_oracle(pkg):
     masks, iou, low = pred.predict_torch(pts.cuda(), lab.int().cuda(), return_logits=True)
     rm, ri, rl = osam.predict_torch(sd, cfg.oracle_kw(), state, pts, lab)
     assert maxdiff(low, rl) < 5 * TOL and maxdiff(iou, ri) < 5 * TOL and maxdiff(masks, rm) < 5 * TOL
+
+
+def test_generator_with_crop_layers_and_rle(pkg):
+    """One extra crop layer (four overlapping crops, their own embeddings and point grids, edge filter, NMS between
+    crops) and run-length output, against the oracle."""
+    from oracle import sam as osam
+    sa = pkg.segment_anything
+    cfg = pkg.synth.SAM_ARCHS["tiny"]
+    sd = pkg.synth.sam_state_dict(cfg, seed=5)
+    sam = sa.sam_model_registry["tiny"](state_dict=sd, device="cuda")
+    # Masks of random weights cover their whole crop at threshold 0, and the crop-edge filter then drops every mask
+    # of the inner crops; a raised threshold leaves small blobs, so two crops contribute.
+    sam.mask_threshold = 0.5
+    img = np.random.default_rng(3).integers(0, 256, size=(240, 320, 3), dtype=np.uint8)
+    kw = dict(points_per_side=4, points_per_batch=7, pred_iou_thresh=-10.0, stability_score_thresh=0.0, box_nms_thresh=0.9,
+              crop_n_layers=1, crop_nms_thresh=0.95, crop_overlap_ratio=0.3, crop_n_points_downscale_factor=2,
+              output_mode="uncompressed_rle")
+    recs = sa.SamAutomaticMaskGenerator(sam, **kw).generate(img)
+    ref = osam.generate(sd, cfg.oracle_kw(), img, mask_threshold=0.5, **kw)
+    assert len(recs) == len(ref) >= 2 and len({tuple(r["crop_box"]) for r in ref}) >= 2       # more than one crop contributes
+    amg = sa.amg
+    for a, b in zip(recs, ref):
+        assert a["point_coords"] == b["point_coords"] and a["crop_box"] == b["crop_box"]
+        assert abs(a["predicted_iou"] - b["predicted_iou"]) < TOL
+        ma, mb = amg.rle_to_mask(a["segmentation"]), osam.rle_to_mask(b["segmentation"])
+        assert ma.shape == img.shape[:2] and float((ma != mb).mean()) < 2e-3
+        assert a["area"] == amg.area_from_rle(a["segmentation"])
+        assert np.abs(np.array(a["bbox"]) - np.array(b["bbox"])).max() <= 1
