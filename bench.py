@@ -27,6 +27,12 @@ from __graft_entry__ import load_package  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
 NPROP, SIZE, FOLD = 64, 518, 0
+# kernel instantiation behind each launch-policy variant (csrc/gemm.hip, csrc/gemm3.hip)
+RING_KERNELS = {3: "gemm_tn_ring_kernel<bf16, *, 2, 4, 8, 4, 2, 3> (256x256 tile)",
+                5: "gemm_tn_ring_kernel<bf16, *, 2, 2, 8, 4, 2, 3> (256x128 tile)",
+                6: "gemm_tn_ring_kernel<bf16, *, 2, 2, 4, 4, 3, 3> (128x128 tile)",
+                7: "gemm_tn_ring_kernel<bf16, *, 2, 2, 2, 4, 4, 3> (64x128 tile)",
+                8: "gemm_tn_ring_kernel<bf16, *, 2, 4, 8, 4, 2, 4, true> (256x256 tile, pair fills)"}
 
 
 def build_args(device, dtype):
@@ -166,10 +172,15 @@ def main():
 
     if rank == 0:
         # Every MFMA GEMM launch of the sampled step was timed with events on its stream.  The dominant
-        # kernel is the 256 x 128 ring shape (variant 5: the AlphaCLIP products, 58 % of the GPU time);
-        # the smaller ring shapes that run the two alignment towers are summed under "all_gemm".
+        # kernel is the ring shape with the largest summed time (the AlphaCLIP products run on two of them:
+        # 256 x 256 with pair fills for QKV and FC2, 256 x 128 for the projection and FC1); every launch,
+        # the smaller shapes of the two alignment towers included, is summed under "all_gemm".
         timed = [(p[0].elapsed_time(p[1]), p[2], p[3]) for p in prof]
-        dom = [t for t in timed if t[2] == 5] or timed
+        by_variant = {}
+        for t in timed:
+            by_variant[t[2]] = by_variant.get(t[2], 0.0) + t[0]
+        dom_variant = max(by_variant, key=by_variant.get) if by_variant else None
+        dom = [t for t in timed if t[2] == dom_variant] or timed
         flops, ms = sum(t[1] for t in dom), sum(t[0] for t in dom)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         ms_all = sum(t[0] for t in timed)
@@ -185,7 +196,7 @@ def main():
                        "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}"},
             "miou": float(miou), "fb_iou": float(fb_iou),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(), "kernel": "gemm_tn_ring_kernel<bf16, *, 2, 2, 8, 4, 2, 3> (256x128 tile)",
+                         "traffic": pmc_traffic(), "kernel": RING_KERNELS.get(dom_variant, f"gemm variant {dom_variant}"),
                          "launches": len(dom), "avg_launch_us": ms * 1e3 / max(len(dom), 1), "sampled_steps": 1,
                          "share_of_step": ms / (elapsed / args.steps * 1e3), "all_gemm": all_gemm},
         }

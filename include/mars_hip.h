@@ -50,9 +50,9 @@ int marship_gemm(const MarsGemm* g, void* stream);
 /* Tuning hook (no reference counterpart): selects the GEMM kernel variant, returns the previous
  * one. 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
  * 3 = LDS-DMA ring 256x256, 4 = chosen by shape (default), 5 = ring 256x128, 6 = ring 128x128,
- * 7 = ring 64x128. */
+ * 7 = ring 64x128, 8 = ring 256x256 with pair fills. */
 int marship_set_gemm_variant(int variant);
-/* The variant marship_gemm would run for this product (5, 6 or 7 under "chosen by shape"); used by the
+/* The variant marship_gemm would run for this product (5, 6, 7 or 8 under "chosen by shape"); used by the
  * benchmark to attribute launch times to kernels.  No reference counterpart. */
 int marship_gemm_variant_for(const MarsGemm* g);
 

@@ -164,15 +164,15 @@ static int g_gemm_variant = 4;
 
 // Tuning hook: 0 = register-staged 128x128, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
 // 3 = LDS-DMA ring 256x256, 4 = choose by shape (default), 5 = LDS-DMA ring 256x128,
-// 6 = LDS-DMA ring 128x128, 7 = LDS-DMA ring 64x128.
+// 6 = LDS-DMA ring 128x128, 7 = LDS-DMA ring 64x128, 8 = LDS-DMA ring 256x256 with pair fills.
 extern "C" int marship_set_gemm_variant(int v) {
     const int old = g_gemm_variant;
-    if (v >= 0 && v <= 7) g_gemm_variant = v;
+    if (v >= 0 && v <= 9) g_gemm_variant = v;
     return old;
 }
 
 // the kernel variant the launch policy picks for a product (the variant set by the tuning hook, or, for
-// "choose by shape", the ring shape: 5, 6 or 7)
+// "choose by shape", the ring shape: 5, 6, 7 or 8)
 static int pick_variant(const MarsGemm* g) {
     int v = g_gemm_variant;
     if (v == 4) {
@@ -180,6 +180,10 @@ static int pick_variant(const MarsGemm* g) {
         // the 128 x 128 shape spreads the product over more CUs
         const int64_t big = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256) * g->nb0 * g->nb1;
         v = big >= 192 ? 5 : 6;
+        // long products without an activation run faster on the 256 x 256 shape with pair fills (one barrier
+        // per 128 bytes of K); an activation epilogue, or a short product whose time is mostly its residual
+        // traffic, is better hidden behind the second 256 x 128 workgroup of the CU
+        if (v == 5 && g->in_dtype == 1 && g->act == 0 && (g->N >= 2048 || g->K >= 2048)) v = 8;
         // fewer 128 x 128 tiles than about half the CUs: halve the tile height to spread the work
         const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128) * g->nb0 * g->nb1;
         if (v == 6 && t128 < 150) v = 7;

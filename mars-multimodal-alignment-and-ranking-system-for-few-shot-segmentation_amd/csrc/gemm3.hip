@@ -96,8 +96,15 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
 
 // NWR x NWC waves, each FM x FN fragments (16 FM x 16 FN outputs); WPE = waves per SIMD the register
 // budget must allow (workgroups per CU x waves per workgroup / 4).
-template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE, int RING>
+//
+// PAIR: the two 64-byte halves of a 128-byte line are requested back to back (steps 2p and 2p+1 of every row
+// piece in consecutive instructions), so the second request finds the line the first one brought into the
+// CU's vector cache instead of fetching it from L2 again one step later, when it has long been evicted.  The
+// ring then has four slots, filled a pair at a time at the top of every odd step (the pair of slots steps
+// 2p, 2p+1 used is free once the fragments of step 2p+1 are in registers), and one barrier per pair.
+template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE, int RING, bool PAIR = false>
 __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g, int group_m) {
+    static_assert(!PAIR || RING == 4 || RING == 5, "pair fills need a ring of four or five slots");
     constexpr int BM = 16 * FM * NWR, WN = 16 * FN, BN = WN * NWC, NWAVES = NWR * NWC;
     constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
     static_assert((BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0, "DMA pieces must divide among the waves");
@@ -171,6 +178,22 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         }
         (std::make_integer_sequence<int, PIECES>{});
     };
+    // pair fills: both halves of the lines of piece P, one instruction behind the other
+    auto issue_pair_piece = [&](int s, int slot0, int slot1, auto p_tag) {
+        issue_piece(s, slot0, p_tag);
+        issue_piece(s + 1, slot1, p_tag);
+    };
+    auto issue_pair_row = [&](int s, int slot0, int slot1, auto m_tag) {
+        constexpr int m = decltype(m_tag)::value;
+        [&]<int... P>(std::integer_sequence<int, P...>) {
+            ((P * FM / PIECES == m ? issue_pair_piece(s, slot0, slot1, std::integral_constant<int, P>{}) : (void)0), ...);
+        }
+        (std::make_integer_sequence<int, PIECES>{});
+    };
+    auto issue_pair = [&](int s, int slot0, int slot1) {
+        [&]<int... P>(std::integer_sequence<int, P...>) { (issue_pair_piece(s, slot0, slot1, std::integral_constant<int, P>{}), ...); }
+        (std::make_integer_sequence<int, PIECES>{});
+    };
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -225,20 +248,44 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     // s_waitcnt vmcnt(0) in front of any ds_read it can see, draining the ring.  `slot` is the ring
     // slot of step s.  MAIN steps (s + 3 < ns) have no conditions in them; the reads of the last
     // step fetch a stale slot into registers nobody uses.
-#define MARS_PHASE(CA, CB, NA, NB, s_, MAIN)                                                         \
+#define MARS_PHASE(CA, CB, NA, NB, s_, ODD)                                                          \
     {                                                                                                 \
         const int nslot = slot + 1 == RING ? 0 : slot + 1;                                            \
-        if (MAIN || (s_) + 1 < ns) {                                                                  \
-            if (MAIN || (s_) + RING - 1 < ns) MARS_WAIT_VM((RING - 2) * PIECES);                      \
-            else MARS_WAIT_VM(0);                                                                     \
-            __builtin_amdgcn_s_barrier();                                                             \
-            asm volatile("" ::: "memory");                                                            \
+        bool more;                                                                                    \
+        if constexpr (PAIR && RING == 4) {                                                            \
+            if ((ODD) && (s_) + 1 < ns) {                                                             \
+                MARS_WAIT_VM(0);                                                                      \
+                __builtin_amdgcn_s_barrier();                                                         \
+                asm volatile("" ::: "memory");                                                        \
+            }                                                                                         \
+            more = MARS_EXP_DMA && (ODD) && (s_) + 3 < ns;                                            \
+        } else if constexpr (PAIR) {                                                                  \
+            if ((s_) + 1 < ns) {                                                                      \
+                if (ODD) {                                                                            \
+                    if ((s_) + 3 < ns) MARS_WAIT_VM(2 * PIECES);                                      \
+                    else MARS_WAIT_VM(0);                                                             \
+                }                                                                                     \
+                __builtin_amdgcn_s_barrier();                                                         \
+                asm volatile("" ::: "memory");                                                        \
+            }                                                                                         \
+            more = MARS_EXP_DMA && !(ODD) && (s_) + 4 < ns;                                           \
+        } else {                                                                                      \
+            if ((s_) + 1 < ns) {                                                                      \
+                if ((s_) + RING - 1 < ns) MARS_WAIT_VM((RING - 2) * PIECES);                          \
+                else MARS_WAIT_VM(0);                                                                 \
+                __builtin_amdgcn_s_barrier();                                                         \
+                asm volatile("" ::: "memory");                                                        \
+            }                                                                                         \
+            more = MARS_EXP_DMA && (s_) + RING < ns;                                                  \
         }                                                                                             \
-        const bool more = MARS_EXP_DMA && (MAIN || (s_) + RING < ns);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         auto row = [&](auto mi_tag) {                                                                 \
             constexpr int M_ = decltype(mi_tag)::value;                                               \
-            if (more) issue_row((s_) + RING, slot, mi_tag);                                           \
+            if constexpr (PAIR) {                                                                     \
+                if (more) issue_pair_row((s_) + RING - 1, (slot + RING - 1) % RING, slot, mi_tag);    \
+            } else {                                                                                  \
+                if (more) issue_row((s_) + RING, slot, mi_tag);                                       \
+            }                                                                                         \
             if (MARS_EXP_READ) {                                                                      \
                 [&]<int... J>(std::integer_sequence<int, J...>) {                                     \
                     ((J * FM / (FM + FN) == M_ ? read_one(NA, NB, nslot, std::integral_constant<int, J>{}) : (void)0), ...); \
@@ -255,11 +302,17 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         slot = nslot;                                                                                 \
     }
 
+    if constexpr (PAIR) {                                  // ns is even: K spans a multiple of 128 bytes
+        issue_pair(0, 0, 1);
+        if (ns > 2) { issue_pair(2, 2, 3); MARS_WAIT_VM(2 * PIECES); }
+        else MARS_WAIT_VM(0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < RING; ++i)
-        if (i < ns) issue(i, i);
-    if (ns >= RING) MARS_WAIT_VM((RING - 1) * PIECES);
-    else MARS_WAIT_VM(0);
+        for (int i = 0; i < RING; ++i)
+            if (i < ns) issue(i, i);
+        if (ns >= RING) MARS_WAIT_VM((RING - 1) * PIECES);
+        else MARS_WAIT_VM(0);
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     read_frags(faA, fbA, 0);
@@ -269,7 +322,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     int slot = 0;
     for (int s = 0; s < ns; s += 2) {
         MARS_PHASE(faA, fbA, faB, fbB, s, false)
-        if (s + 1 < ns) MARS_PHASE(faB, fbB, faA, fbA, s + 1, false)
+        if (s + 1 < ns) MARS_PHASE(faB, fbB, faA, fbA, s + 1, true)
     }
 #undef MARS_PHASE
 #undef MARS_WAIT_VM
@@ -416,16 +469,16 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
 // M-tiles per raster group (tuning knob of the diagnostic tools)
 int mars_ring_group_m = 8;
 
-template <int NWR, int NWC, int FM, int FN, int WPE, int RING>
+template <int NWR, int NWC, int FM, int FN, int WPE, int RING, bool PAIR = false>
 static void ring_launch(const MarsGemm& g, hipStream_t s) {
     constexpr int BM = 16 * FM * NWR, BN = 16 * FN * NWC;
     dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), g.nb0 * g.nb1), block(64 * NWR * NWC);
     if (g.in_dtype == 1) {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, FN, WPE, RING, PAIR>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, FN, WPE, RING, PAIR>), grid, block, 0, s, g, mars_ring_group_m);
     } else {
-        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
-        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, FN, WPE, RING>), grid, block, 0, s, g, mars_ring_group_m);
+        if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<float, __bf16, NWR, NWC, FM, FN, WPE, RING, PAIR>), grid, block, 0, s, g, mars_ring_group_m);
+        else hipLaunchKernelGGL((gemm_tn_ring_kernel<float, float, NWR, NWC, FM, FN, WPE, RING, PAIR>), grid, block, 0, s, g, mars_ring_group_m);
     }
 }
 
@@ -436,5 +489,7 @@ void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape) {
     if (shape == 0) ring_launch<2, 4, 8, 4, 2, 3>(g, s);
     else if (shape == 1) ring_launch<2, 2, 8, 4, 2, 3>(g, s);
     else if (shape == 2) ring_launch<2, 2, 4, 4, 3, 3>(g, s);
-    else ring_launch<2, 2, 2, 4, 4, 3>(g, s);
+    else if (shape == 3) ring_launch<2, 2, 2, 4, 4, 3>(g, s);
+    else if (shape == 4) ring_launch<2, 4, 8, 4, 2, 4, true>(g, s);         // 256 x 256 with pair fills (128 KiB LDS)
+    else ring_launch<2, 4, 8, 4, 2, 5, true>(g, s);                          // the same with five slots (160 KiB LDS)
 }

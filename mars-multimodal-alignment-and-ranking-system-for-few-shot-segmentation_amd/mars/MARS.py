@@ -62,6 +62,9 @@ class MARS:
         # lines 85-89; the AlphaCLIP batch needs nothing from the alignment towers, so with MARS_OVERLAP=1 it
         # is queued first, on a stream of its own, and the towers run beside it.  Off by default: at 64
         # proposals the batch already fills the chip and sharing it cost 6 % (52.9 against 49.9 ms a query).
+        # Giving the towers a CU range of their own (a stream with a CU mask, 24-64 of the 256 CUs) was worse
+        # still, 90-109 ms: their products fill most of the chip one tile per CU, so on a fifth of the CUs
+        # they take five times as long and the batch waits for them.
         text_alpha_clip = [f"a {name}."] if description == "" else [f"a {name}, {description}."]
         fmm = self.filtering_merging_component
         if self.overlap and hasattr(fmm, "prefetch"):

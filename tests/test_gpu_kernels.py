@@ -45,7 +45,7 @@ def _act(z, act):
     return F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else (F.relu(z) if act == 3 else z))
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7])
+@pytest.mark.parametrize("variant", [5, 6, 7, 8])
 @pytest.mark.parametrize("act", [1, 3])
 def test_gemm_fast_epilogue_activations(pkg, cuda, variant, act):
     """erf-GELU and ReLU on the register-direct epilogue of the ring kernels (aligned rows, no residual)."""
@@ -81,7 +81,7 @@ def test_gemm_epilogue(pkg, cuda, act):
     assert float((outb.float() - z).abs().max()) < 0.05
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (513, 257, 64), (256, 512, 1024), (70, 1100, 320)])
 def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):
