@@ -90,7 +90,7 @@ def cpu_baseline(pkg, sds, sample_props=4):
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 counter passes (FETCH_SIZE and
     WRITE_SIZE, separate runs, FETCH_SIZE doubled for gfx950; see tools/pmc_traffic.py), or None."""
-    path = os.path.join(ROOT, "profiles", "r1_v6_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_v7_pmc_traffic.json")
     try:
         return float(json.load(open(path))["bytes_per_launch"])
     except (OSError, KeyError, ValueError):

@@ -19,7 +19,8 @@ for kind in ("fetch", "write"):
         w.writeheader()
         for r in rows:
             w.writerow({k: r[k] for k in w.fieldnames})
-# the dominant kernel: the 256 x 128 ring instantiations with bf16 inputs (either output type)
-dominant = "gemm_tn_ring_kernel<bool _Accum, 2, 2, 8, 4, 2, 3>|gemm_tn_ring_kernelIDF16bDF16bLi2ELi2ELi8ELi4ELi2ELi3E"
+# the dominant kernel: the 256 x 256 pair-fill ring instantiations (bf16 inputs, either output type: the AlphaCLIP
+# QKV and FC2 products); rocprofv3 prints some names demangled and some not
+dominant = "2, 4, 8, 4, 2, 4, true>|Li2ELi4ELi8ELi4ELi2ELi4ELb1E"
 subprocess.check_call([sys.executable, "tools/pmc_traffic.py", f"{src}/fetch/{tag}_counter_collection.csv",
                        f"{src}/write/{tag}_counter_collection.csv", dominant, f"{dst}/{tag}_pmc_traffic.json"])
