@@ -87,17 +87,23 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     for (int c = lane; c < ld; c += 64) o[c] = c < T ? pr[c] * (dr[c] - s) * scale : 0.f;
 }
 
-// 64 columns x 4 row groups per block
-__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ x, int64_t ld, int r0, int r1, int D,
-                                                       float* __restrict__ out) {
-    __shared__ float sm[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), gq = threadIdx.x >> 6;
+// 64 columns x 16 row groups per block
+__global__ __launch_bounds__(1024) void col_mean_kernel(const float* __restrict__ x, int64_t ld, int r0, int r1, int D,
+                                                        float* __restrict__ out) {
+    __shared__ float sm[16][64];
+    const int lane = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < D)
-        for (int r = r0 + gq; r < r1; r += 4) s += x[(int64_t)r * ld + c];
-    sm[gq][threadIdx.x & 63] = s;
+        for (int r = r0 + gq; r < r1; r += 16) s += x[(int64_t)r * ld + c];
+    sm[gq][lane] = s;
     __syncthreads();
-    if (gq == 0 && c < D) out[c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)(r1 - r0);
+    if (gq == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][lane];
+        out[c] = t / (float)(r1 - r0);
+    }
 }
 
 __global__ __launch_bounds__(1024) void cam_head_kernel(const float* __restrict__ f, const float* __restrict__ proj,
@@ -106,11 +112,22 @@ __global__ __launch_bounds__(1024) void cam_head_kernel(const float* __restrict_
     __shared__ float g[1024], dg[1024];
     __shared__ float sm[16];
     const int t = threadIdx.x;
+    // g = f . proj: column t % E, the rows dealt to the 1024 / E thread groups (row-contiguous, coalesced reads)
+    const int ngrp = 1024 / E > 0 ? 1024 / E : 1;
+    {
+        float part = 0.f;
+        const int e = t % E, grp = t / E;
+        if (grp < ngrp)
+            for (int d = grp; d < D; d += ngrp) part += f[d] * proj[(int64_t)d * E + e];
+        dg[t] = part;
+        __syncthreads();
+    }
     float ge = 0.f;
     if (t < E) {
-        for (int d = 0; d < D; ++d) ge += f[d] * proj[(int64_t)d * E + t];
+        for (int k = 0; k < ngrp; ++k) ge += dg[k * E + t];
         g[t] = ge;
     }
+    __syncthreads();
     const float t0 = t < E ? text[t] : 0.f, t1 = t < E ? text[E + t] : 0.f;
     const float ng = sqrtf(block_reduce_sum(ge * ge, sm));
     const float n0 = sqrtf(block_reduce_sum(t0 * t0, sm));
@@ -127,10 +144,13 @@ __global__ __launch_bounds__(1024) void cam_head_kernel(const float* __restrict_
     const float dot = block_reduce_sum(gh * dgh, sm);
     if (t < E) dg[t] = (dgh - gh * dot) / ng;
     __syncthreads();
-    for (int d = t; d < D; d += blockDim.x) {
+    // df = proj . dg: one wave per row, lanes along the row
+    const int lane = t & 63, wv = t >> 6;
+    for (int d = wv; d < D; d += 16) {
         float s = 0.f;
-        for (int e = 0; e < E; ++e) s += proj[(int64_t)d * E + e] * dg[e];
-        df[d] = s;
+        for (int e = lane; e < E; e += 64) s += proj[(int64_t)d * E + e] * dg[e];
+        s = wave_sum(s);
+        if (lane == 0) df[d] = s;
     }
 }
 
@@ -180,7 +200,7 @@ extern "C" int marship_softmax_bwd(const float* P, const float* dP, float* dS, i
 
 extern "C" int marship_col_mean(const float* x, int64_t ld, int r0, int r1, int D, float* out, void* stream) {
     MARS_CHECK(x && out && r1 > r0 && D > 0 && ld >= D, "col_mean: bad arguments");
-    hipLaunchKernelGGL(col_mean_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, r0, r1, D, out);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((D + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, ld, r0, r1, D, out);
     MARS_LAUNCH_CHECK();
     return 0;
 }
