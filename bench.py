@@ -32,7 +32,9 @@ RING_KERNELS = {3: "gemm_tn_ring_kernel<bf16, *, 2, 4, 8, 4, 2, 3> (256x256 tile
                 5: "gemm_tn_ring_kernel<bf16, *, 2, 2, 8, 4, 2, 3> (256x128 tile)",
                 6: "gemm_tn_ring_kernel<bf16, *, 2, 2, 4, 4, 3, 3> (128x128 tile)",
                 7: "gemm_tn_ring_kernel<bf16, *, 2, 2, 2, 4, 4, 3> (64x128 tile)",
-                8: "gemm_tn_ring_kernel<bf16, *, 2, 4, 8, 4, 2, 4, true> (256x256 tile, pair fills)"}
+                8: "gemm_tn_ring_kernel<bf16, *, 2, 4, 8, 4, 2, 4, true> (256x256 tile, pair fills)",
+                10: "gemm_tn_ring_kernel<bf16, *, 2, 2, 2, 4, 2, 6, true> (64x128 tile, pair fills)",
+                11: "gemm_tn_ring_kernel<bf16, *, 2, 2, 4, 4, 2, 4, true> (128x128 tile, pair fills)"}
 
 
 def build_args(device, dtype):
@@ -90,11 +92,13 @@ def cpu_baseline(pkg, sds, sample_props=4):
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 counter passes (FETCH_SIZE and
     WRITE_SIZE, separate runs, FETCH_SIZE doubled for gfx950; see tools/pmc_traffic.py), or None."""
-    path = os.path.join(ROOT, "profiles", "r1_v7_pmc_traffic.json")
-    try:
-        return float(json.load(open(path))["bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):   # newest tag first
+        try:
+            return float(json.load(open(path))["bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def main():
@@ -172,8 +176,8 @@ def main():
 
     if rank == 0:
         # Every MFMA GEMM launch of the sampled step was timed with events on its stream.  The dominant
-        # kernel is the ring shape with the largest summed time (the AlphaCLIP products run on two of them:
-        # 256 x 256 with pair fills for QKV and FC2, 256 x 128 for the projection and FC1); every launch,
+        # kernel is the ring shape with the largest summed time (the AlphaCLIP products run on three of them:
+        # 256 x 256 with pair fills for QKV and FC2, 256 x 128 for FC1, 128 x 128 for the projection); every launch,
         # the smaller shapes of the two alignment towers included, is summed under "all_gemm".
         timed = [(p[0].elapsed_time(p[1]), p[2], p[3]) for p in prof]
         by_variant = {}

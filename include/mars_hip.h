@@ -50,11 +50,18 @@ int marship_gemm(const MarsGemm* g, void* stream);
 /* Tuning hook (no reference counterpart): selects the GEMM kernel variant, returns the previous
  * one. 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
  * 3 = LDS-DMA ring 256x256, 4 = chosen by shape (default), 5 = ring 256x128, 6 = ring 128x128,
- * 7 = ring 64x128, 8 = ring 256x256 with pair fills. */
+ * 7 = ring 64x128, 8 = ring 256x256 with pair fills, 9 / 10 / 11 = 128x128 (eight slots), 64x128 (six slots),
+ * 128x128 (four slots) with pair fills. */
 int marship_set_gemm_variant(int variant);
-/* The variant marship_gemm would run for this product (5, 6, 7 or 8 under "chosen by shape"); used by the
- * benchmark to attribute launch times to kernels.  No reference counterpart. */
+/* The variant marship_gemm would run for this product (5, 6, 7, 8, 10 or 11 under "chosen by shape"); used by
+ * the benchmark to attribute launch times to kernels.  No reference counterpart. */
 int marship_gemm_variant_for(const MarsGemm* g);
+/* Tuning hook (no reference counterpart): under "chosen by shape" a tall unbatched product whose tiles would
+ * leave most CUs idle in their last round runs as two launches, rows [0, r) on the large tile and rows [r, M)
+ * as a product of their own.  marship_set_gemm_split(0) keeps every product in one launch; returns the
+ * previous setting.  marship_gemm_split_rows returns r (M when the product is not split). */
+int marship_set_gemm_split(int on);
+int marship_gemm_split_rows(const MarsGemm* g);
 
 /* ---- ViT glue ------------------------------------------------------------------ */
 /* nn.LayerNorm over the last dim (dinov2 vision_transformer.py:97 eps 1e-6; clip/model.py:265-271

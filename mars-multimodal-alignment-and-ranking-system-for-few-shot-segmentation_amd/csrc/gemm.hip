@@ -164,36 +164,85 @@ static int g_gemm_variant = 4;
 
 // Tuning hook: 0 = register-staged 128x128, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
 // 3 = LDS-DMA ring 256x256, 4 = choose by shape (default), 5 = LDS-DMA ring 256x128,
-// 6 = LDS-DMA ring 128x128, 7 = LDS-DMA ring 64x128, 8 = LDS-DMA ring 256x256 with pair fills.
+// 6 = LDS-DMA ring 128x128, 7 = LDS-DMA ring 64x128, 8 = LDS-DMA ring 256x256 with pair fills,
+// 9 = 128x128 with pair fills and eight slots, 10 = 64x128 with pair fills and six slots,
+// 11 = 128x128 with pair fills and four slots.
 extern "C" int marship_set_gemm_variant(int v) {
     const int old = g_gemm_variant;
-    if (v >= 0 && v <= 9) g_gemm_variant = v;
+    if (v >= 0 && v <= 11) g_gemm_variant = v;
+    return old;
+}
+
+// Tuning hook: 1 (default) lets "choose by shape" cut a tall product into two launches when the tiles of one
+// launch would leave most of the chip idle in their last round; 0 keeps every product in one launch.
+static int g_gemm_split = 1;
+extern "C" int marship_set_gemm_split(int on) {
+    const int old = g_gemm_split;
+    g_gemm_split = on != 0;
     return old;
 }
 
 // the kernel variant the launch policy picks for a product (the variant set by the tuning hook, or, for
-// "choose by shape", the ring shape: 5, 6, 7 or 8)
+// "choose by shape", the ring shape: 5, 6, 7, 8, 10 or 11)
 static int pick_variant(const MarsGemm* g) {
     int v = g_gemm_variant;
     if (v == 4) {
         // the 256 x 128 ring shape needs about a full wave of workgroups to pay off; below that
-        // the 128 x 128 shape spreads the product over more CUs
+        // the 128 x 128 shape spreads the product over more CUs (bf16: with pair fills)
         const int64_t big = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256) * g->nb0 * g->nb1;
-        v = big >= 192 ? 5 : 6;
+        v = big >= 192 ? 5 : (g->in_dtype == 1 ? 11 : 6);
         // long products without an activation run faster on the 256 x 256 shape with pair fills (one barrier
         // per 128 bytes of K); an activation epilogue, or a short product whose time is mostly its residual
         // traffic, is better hidden behind the second 256 x 128 workgroup of the CU
         if (v == 5 && g->in_dtype == 1 && g->act == 0 && (g->N >= 2048 || g->K >= 2048)) v = 8;
-        // fewer 128 x 128 tiles than about half the CUs: halve the tile height to spread the work
+        // a short, narrow bf16 product (the attention projection) is mostly its f32 residual traffic: the
+        // 128 x 128 pair-fill shape balances 2.3 rounds of 256-row tiles better (4.5 rounds of its own)
+        else if (v == 5 && g->in_dtype == 1 && g->act == 0 && g->out_dtype == 0) v = 11;
+        // few 128 x 128 tiles: halve the tile height to spread the work (bf16: up to about one tile per
+        // CU, on the pair-fill shape; f32: up to about half the CUs)
         const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128) * g->nb0 * g->nb1;
+        if (v == 11 && t128 < 300) v = 10;
         if (v == 6 && t128 < 150) v = 7;
     }
     return v;
 }
 
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            n = cus;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+// Rows the first of two launches covers, or M when the product runs as one launch.  The 256-row shapes keep
+// one (256 x 256) or two (256 x 128) workgroups on a CU, so a product runs in rounds of that many tiles; when
+// the last round is less than 0.6 full (the AlphaCLIP projection and FC2: 2.27 rounds) the rows of the full
+// rounds go out as one launch and the rest as a launch of their own, which the policy then gives a smaller tile.
+static int split_rows(const MarsGemm* g, int v) {
+    if (!g_gemm_split || g_gemm_variant != 4 || g->nb0 * g->nb1 != 1 || v != 8) return g->M;
+    const int bn = v == 8 ? 256 : 128, slots = cu_count() * (v == 8 ? 1 : 2);
+    const int64_t ntm = (g->M + 255) / 256, ntn = (g->N + bn - 1) / bn, tiles = ntm * ntn;
+    const int64_t full = tiles / slots, rem = tiles % slots;
+    if (full < 1 || full > 4 || rem == 0 || rem * 10 > (int64_t)slots * 6) return g->M;
+    const int64_t row_tiles = full * slots / ntn;
+    if (row_tiles < 1 || row_tiles >= ntm) return g->M;
+    return (int)(row_tiles * 256);
+}
+
 extern "C" int marship_gemm_variant_for(const MarsGemm* g) {
     MARS_CHECK(g && g->M > 0 && g->N > 0 && g->nb0 > 0 && g->nb1 > 0, "gemm_variant_for: bad shape");
     return pick_variant(g);
+}
+
+extern "C" int marship_gemm_split_rows(const MarsGemm* g) {
+    MARS_CHECK(g && g->M > 0 && g->N > 0 && g->nb0 > 0 && g->nb1 > 0, "gemm_split_rows: bad shape");
+    return split_rows(g, pick_variant(g));
 }
 
 extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
@@ -215,6 +264,22 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (g_gemm_variant != 0) {
         const int v = pick_variant(g);
+        const int rows = split_rows(g, v);
+        if (rows < g->M) {
+            // rows [0, rows) fill whole rounds of tiles; the rest is a product of its own
+            MarsGemm head = *g, tail = *g;
+            head.M = rows;
+            tail.M = g->M - rows;
+            tail.A = (const char*)g->A + (int64_t)rows * g->lda * es;
+            tail.C = (char*)g->C + (int64_t)rows * g->ldc * (g->out_dtype == 1 ? 2 : 4);
+            if (g->residual) tail.residual = g->residual + (int64_t)rows * g->ldr;
+            mars_gemm_ring_launch(head, s, v - 4);
+            MARS_LAUNCH_CHECK();
+            const int vt = pick_variant(&tail);
+            mars_gemm_ring_launch(tail, s, vt - 4);
+            MARS_LAUNCH_CHECK();
+            return 0;
+        }
         if (v == 3 || v >= 5) mars_gemm_ring_launch(*g, s, v == 3 ? 0 : v - 4);
         else mars_gemm_glds_launch(*g, s, v);
         MARS_LAUNCH_CHECK();

@@ -100,11 +100,11 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
 // PAIR: the two 64-byte halves of a 128-byte line are requested back to back (steps 2p and 2p+1 of every row
 // piece in consecutive instructions), so the second request finds the line the first one brought into the
 // CU's vector cache instead of fetching it from L2 again one step later, when it has long been evicted.  The
-// ring then has four slots, filled a pair at a time at the top of every odd step (the pair of slots steps
-// 2p, 2p+1 used is free once the fragments of step 2p+1 are in registers), and one barrier per pair.
+// ring then has an even number of slots, filled a pair at a time at the top of every odd step (the pair of slots
+// steps 2p, 2p+1 used is free once the fragments of step 2p+1 are in registers), and one barrier per pair.
 template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE, int RING, bool PAIR = false>
 __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g, int group_m) {
-    static_assert(!PAIR || RING == 4 || RING == 5, "pair fills need a ring of four or five slots");
+    static_assert(!PAIR || (RING % 2 == 0 && RING >= 4 && RING <= 8), "pair fills need a ring of four, six or eight slots");
     constexpr int BM = 16 * FM * NWR, WN = 16 * FN, BN = WN * NWC, NWAVES = NWR * NWC;
     constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
     static_assert((BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0, "DMA pieces must divide among the waves");
@@ -231,6 +231,14 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         }
     };
 #define MARS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    // all of this wave's DMAs but those of the youngest `pairs` pairs of steps have landed
+    auto wait_pairs = [&](int pairs) {
+        static_assert(!PAIR || (RING / 2 - 1) * 2 * PIECES <= 63, "vmcnt is a 6-bit count");
+        if (pairs <= 0) MARS_WAIT_VM(0);
+        else if (pairs == 1) MARS_WAIT_VM((2 * PIECES) & 63);
+        else if (pairs == 2) MARS_WAIT_VM((4 * PIECES) & 63);
+        else MARS_WAIT_VM((6 * PIECES) & 63);
+    };
     // fragment read j of a step (B fragments first) into the idle register set
     auto read_one = [&](uint4 (&FA)[FM], uint4 (&FB)[FN], int slot_, auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
@@ -252,23 +260,14 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     {                                                                                                 \
         const int nslot = slot + 1 == RING ? 0 : slot + 1;                                            \
         bool more;                                                                                    \
-        if constexpr (PAIR && RING == 4) {                                                            \
+        if constexpr (PAIR) {                                                                         \
             if ((ODD) && (s_) + 1 < ns) {                                                             \
-                MARS_WAIT_VM(0);                                                                      \
+                /* pairs issued behind the one step s+1 belongs to stay in flight */                  \
+                wait_pairs(min(((s_) + RING - 3) >> 1, (ns >> 1) - 1) - (((s_) + 1) >> 1));           \
                 __builtin_amdgcn_s_barrier();                                                         \
                 asm volatile("" ::: "memory");                                                        \
             }                                                                                         \
-            more = MARS_EXP_DMA && (ODD) && (s_) + 3 < ns;                                            \
-        } else if constexpr (PAIR) {                                                                  \
-            if ((s_) + 1 < ns) {                                                                      \
-                if (ODD) {                                                                            \
-                    if ((s_) + 3 < ns) MARS_WAIT_VM(2 * PIECES);                                      \
-                    else MARS_WAIT_VM(0);                                                             \
-                }                                                                                     \
-                __builtin_amdgcn_s_barrier();                                                         \
-                asm volatile("" ::: "memory");                                                        \
-            }                                                                                         \
-            more = MARS_EXP_DMA && !(ODD) && (s_) + 4 < ns;                                           \
+            more = MARS_EXP_DMA && (ODD) && (s_) + RING - 1 < ns;                                     \
         } else {                                                                                      \
             if ((s_) + 1 < ns) {                                                                      \
                 if ((s_) + RING - 1 < ns) MARS_WAIT_VM((RING - 2) * PIECES);                          \
@@ -303,9 +302,10 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     }
 
     if constexpr (PAIR) {                                  // ns is even: K spans a multiple of 128 bytes
-        issue_pair(0, 0, 1);
-        if (ns > 2) { issue_pair(2, 2, 3); MARS_WAIT_VM(2 * PIECES); }
-        else MARS_WAIT_VM(0);
+#pragma unroll
+        for (int i = 0; i < RING; i += 2)
+            if (i < ns) issue_pair(i, i, i + 1);
+        wait_pairs(min(RING, ns) / 2 - 1);
     } else {
 #pragma unroll
         for (int i = 0; i < RING; ++i)
@@ -491,5 +491,7 @@ void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape) {
     else if (shape == 2) ring_launch<2, 2, 4, 4, 3, 3>(g, s);
     else if (shape == 3) ring_launch<2, 2, 2, 4, 4, 3>(g, s);
     else if (shape == 4) ring_launch<2, 4, 8, 4, 2, 4, true>(g, s);         // 256 x 256 with pair fills (128 KiB LDS)
-    else ring_launch<2, 4, 8, 4, 2, 5, true>(g, s);                          // the same with five slots (160 KiB LDS)
+    else if (shape == 5) ring_launch<2, 2, 4, 4, 1, 8, true>(g, s);         // 128 x 128 with pair fills, eight slots (128 KiB)
+    else if (shape == 6) ring_launch<2, 2, 2, 4, 2, 6, true>(g, s);         // 64 x 128 with pair fills, six slots (72 KiB)
+    else ring_launch<2, 2, 4, 4, 2, 4, true>(g, s);                          // 128 x 128 with pair fills, four slots (64 KiB)
 }

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "marship_gemm": [POINTER(MarsGemm), _P],
     "marship_set_gemm_variant": [_I],
     "marship_gemm_variant_for": [_P],
+    "marship_set_gemm_split": [_I],
+    "marship_gemm_split_rows": [_P],
     "marship_layernorm": [_P, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
     "marship_im2col": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _I, _P],
     "marship_write_prefix_tokens": [_P, _I, _I, _I, _P, _P, _P, _I, _P],

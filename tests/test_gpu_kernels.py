@@ -81,7 +81,7 @@ def test_gemm_epilogue(pkg, cuda, act):
     assert float((outb.float() - z).abs().max()) < 0.05
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (513, 257, 64), (256, 512, 1024), (70, 1100, 320)])
 def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):
@@ -110,6 +110,35 @@ def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):
         assert float((wide[:, N:] + 7.0).abs().max()) == 0.0
     finally:
         lib.marship_set_gemm_variant(old)
+
+
+def test_gemm_split_launch(pkg, cuda):
+    """A tall product the launch policy cuts into two launches (2.27 rounds of 256 x 256 tiles) equals the same
+    product kept in one launch, bit for bit, and the split point is a whole number of row tiles."""
+    lib = pkg.hip.lib()
+    M, N, K = 36928, 1024, 2048
+    a = _rand((M, K), 41, cuda).to(torch.bfloat16)
+    b = (_rand((N, K), 42, cuda) * 0.2).to(torch.bfloat16)
+    bias = _rand((N,), 43, cuda)
+    x0 = _rand((M, N), 44, cuda)
+    g = pkg.hip.MarsGemm()
+    g.M, g.N, g.K, g.nb0, g.nb1, g.in_dtype, g.out_dtype, g.act = M, N, K, 1, 1, 1, 0, 0
+    import ctypes
+    rows = lib.marship_gemm_split_rows(ctypes.byref(g))
+    assert 0 < rows < M and rows % 256 == 0
+    x1 = x0.clone()
+    pkg.ops.linear(a, b, x1, bias=bias, residual=x1)
+    old = lib.marship_set_gemm_split(0)
+    try:
+        assert lib.marship_gemm_split_rows(ctypes.byref(g)) == M
+        x2 = x0.clone()
+        pkg.ops.linear(a, b, x2, bias=bias, residual=x2)
+    finally:
+        lib.marship_set_gemm_split(old)
+    ref = x0[rows - 2:rows + 2] + a[rows - 2:rows + 2].float() @ b.float().t() + bias
+    assert float((x1[rows - 2:rows + 2] - ref).abs().max()) < 5e-3
+    assert float((x1 - x2).abs().max()) < 1e-3      # different tile shapes sum K in different orders
+    assert torch.equal(x1[:rows], x2[:rows])
 
 
 def test_gemm_large_m(pkg, cuda):
