@@ -3,11 +3,11 @@ from __future__ import annotations
 
 from torch.utils.data import DataLoader
 
-from .episodes import DatasetCOCO, DatasetFSS, EpisodeTransform
+from .episodes import DatasetCOCO, DatasetFSS, DatasetPASCAL5i, EpisodeTransform
 
 
 class FSSDataset:
-    datasets = {"coco": DatasetCOCO, "fss": DatasetFSS}
+    datasets = {"coco": DatasetCOCO, "fss": DatasetFSS, "pascal5i": DatasetPASCAL5i}
 
     @classmethod
     def initialize(cls, img_size, datapath, use_original_imgsize):

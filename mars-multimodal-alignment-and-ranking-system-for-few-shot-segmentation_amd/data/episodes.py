@@ -1,6 +1,6 @@
 """Few-shot episode datasets: the reference's batch dictionary (query_img [3, S, S] in [0, 1], query_mask [S, S],
 support_imgs [ns, 3, S, S], support_masks [ns, S, S], class_id, names) for FSS-1000
-(/root/reference/matcher/data/fss.py), COCO-20i (coco.py) and seeded synthetic episodes.
+(/root/reference/matcher/data/fss.py), COCO-20i (coco.py), PASCAL-5i (pascal5i.py) and seeded synthetic episodes.
 
 The image transform is the reference's ``Resize((S, S))`` + ``ToTensor()`` (dataset.py:32-35) on Pillow images:
 bilinear with antialiasing, then /255.  Masks are resized with nearest-neighbour sampling (fss.py:38, coco.py:47).
@@ -114,6 +114,113 @@ class DatasetCOCO(torch.utils.data.Dataset):
                    [cut(self.read_mask(s)) for s in support], query, support, int(c))
         b["org_query_imsize"] = op(query).size
         return b
+
+
+class DatasetPASCAL5i(torch.utils.data.Dataset):
+    """PASCAL-5i from SBD + VOC2012 (/root/reference/matcher/data/pascal5i.py:18-384).
+
+    ``<datapath>/PASCAL5i/sbd/{train,val}.txt, img/, cls/*.mat`` and ``<datapath>/PASCAL5i/VOCdevkit/VOC2012/
+    {ImageSets/Segmentation/{train,val}.txt, JPEGImages, SegmentationClass}``.  Training uses SBD train + val minus
+    everything in the VOC validation list, with the VOC annotation where an image is in both (pascal5i.py:62-88);
+    every other split is the VOC validation list.  The fold's labels are 1-based ``5 fold + 1 .. 5 fold + 5``
+    (``class_ids``, as the reference keeps them); an image belongs to the fold if its label map holds one of
+    them.  Test episodes: 1000, query ``idx mod len``, its classes taken in turn (pascal5i.py:242-273, 321-326),
+    supports drawn with replacement from the class's images until ``shot`` differ from the query.  The batch
+    carries the 255 boundary band as ``query_ignore_idx`` (pascal5i.py:299-316)."""
+
+    def __init__(self, datapath: str, fold: int, transform: EpisodeTransform, split: str, shot: int, use_original_imgsize: bool = False):
+        assert 0 <= fold <= 3
+        self.nfold, self.nclass, self.benchmark, self.shot, self.transform = 4, 20, "pascal5i", shot, transform
+        self.train = split == "train"
+        self.split = "trn" if self.train else "val"
+        self.use_original_imgsize = use_original_imgsize
+        sbd = os.path.join(datapath, "PASCAL5i", "sbd")
+        voc = os.path.join(datapath, "PASCAL5i", "VOCdevkit", "VOC2012")
+        names = lambda p: [str(n) for n in np.atleast_1d(np.loadtxt(p, dtype="str"))]   # noqa: E731
+        voc_trn = names(os.path.join(voc, "ImageSets", "Segmentation", "train.txt"))
+        voc_val = names(os.path.join(voc, "ImageSets", "Segmentation", "val.txt"))
+        if self.train:
+            held = set(voc_val) | set(voc_trn)
+            sbd_list = [n for n in names(os.path.join(sbd, "train.txt")) + names(os.path.join(sbd, "val.txt")) if n not in held]
+            images = [os.path.join(sbd, "img", n + ".jpg") for n in sbd_list] + [os.path.join(voc, "JPEGImages", n + ".jpg") for n in voc_trn]
+            targets = [os.path.join(sbd, "cls", n + ".mat") for n in sbd_list] + [os.path.join(voc, "SegmentationClass", n + ".png") for n in voc_trn]
+        else:
+            images = [os.path.join(voc, "JPEGImages", n + ".jpg") for n in voc_val]
+            targets = [os.path.join(voc, "SegmentationClass", n + ".png") for n in voc_val]
+        self.val_label_set = list(range(fold * 5 + 1, fold * 5 + 6))
+        self.train_label_set = [i for i in range(1, 21) if i not in self.val_label_set]
+        self.label_set = self.class_ids = self.train_label_set if self.train else self.val_label_set
+        # image <-> class tables of the fold; cached beside the data under the reference's file name and keys
+        cache = os.path.join(voc, f"dataset_{fold}_{self.train}.pt")
+        if os.path.exists(cache):
+            d = torch.load(cache, weights_only=True)         # plain containers only; nothing in the file is executed
+            self.img_class_map, self.class_img_map = {int(k): list(v) for k, v in d["icm"].items()}, {int(k): list(v) for k, v in d["cim"].items()}
+            self.images, self.targets = list(d["fi"]), list(d["ft"])
+        else:
+            self.images, self.targets = [], []
+            self.class_img_map = {x: [] for x in self.label_set}
+            self.img_class_map = {}
+            for img, tgt in zip(images, targets):
+                present = set(np.unique(self.load_seg_mask(tgt)).tolist())
+                here = [x for x in self.label_set if x in present]
+                if here:
+                    self.images.append(img)
+                    self.targets.append(tgt)
+                    k = len(self.images) - 1
+                    self.img_class_map[k] = here
+                    for x in here:
+                        self.class_img_map[x].append(k)
+            try:
+                torch.save({"icm": self.img_class_map, "cim": self.class_img_map, "fi": self.images, "ft": self.targets}, cache)
+            except OSError:
+                pass                                         # read-only data directory: rebuild next time
+
+    @staticmethod
+    def load_seg_mask(path: str) -> np.ndarray:
+        """Label map in 0..20 with the 255 boundary band (pascal5i.py:167-188); SBD keeps it in a MATLAB file."""
+        from PIL import Image
+        if path.endswith(".mat"):
+            from scipy.io import loadmat
+            return np.array(loadmat(path)["GTcls"][0]["Segmentation"][0], dtype=np.int_)
+        return np.array(Image.open(path), dtype=np.int_)
+
+    def __len__(self):
+        return len(self.images) if self.train else 1000
+
+    def sample_episode(self, idx: int, offset: int = 0):
+        query = self.images[idx]
+        classes = self.img_class_map[idx]
+        c = classes[offset % len(classes)]
+        support = []
+        while len(support) < self.shot:
+            s = self.images[np.random.choice(self.class_img_map[c], 1, replace=False)[0]]
+            if s != query:
+                support.append(s)
+        return query, support, c
+
+    @staticmethod
+    def extract_binary_mask(mask: torch.Tensor, class_id: int):
+        boundary = (mask / 255).floor()
+        return (mask == class_id + 1).to(mask.dtype), boundary
+
+    def __getitem__(self, idx: int) -> dict:
+        from PIL import Image
+        idx %= len(self.images)
+        offset = idx // len(self.images)                     # 0 after the modulo, as in the reference (pascal5i.py:325-326)
+        query, support, c = self.sample_episode(idx, offset)
+        c -= 1
+        tr = self.transform
+        lab = lambda n: torch.from_numpy(self.load_seg_mask(self.targets[self.images.index(n)]))   # noqa: E731
+        q_pil = Image.open(query).convert("RGB")
+        q_lab = lab(query).float()
+        if not self.use_original_imgsize:
+            q_lab = tr.mask(q_lab)
+        q_mask, q_ign = self.extract_binary_mask(q_lab, c)
+        s_pairs = [self.extract_binary_mask(tr.mask(lab(s)), c) for s in support]
+        return {"query_img": tr(q_pil), "query_mask": q_mask, "query_name": query, "query_ignore_idx": q_ign,
+                "org_query_imgsize": q_pil.size, "support_imgs": torch.stack([tr(Image.open(s)) for s in support]),
+                "support_masks": torch.stack([m for m, _ in s_pairs]), "support_names": support,
+                "support_ignore_idxs": torch.stack([g for _, g in s_pairs]), "class_id": torch.tensor(c)}
 
 
 class DatasetSynthetic(torch.utils.data.Dataset):

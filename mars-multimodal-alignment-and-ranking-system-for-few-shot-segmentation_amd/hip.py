@@ -11,7 +11,7 @@ import re
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmars_hip.so")
+LIB_PATH = os.environ.get("MARS_HIP_LIB") or os.path.join(_HERE, "csrc", "libmars_hip.so")   # override: A/B runs of two builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mars_hip.h")
 
 F32, BF16 = 0, 1

@@ -15,7 +15,10 @@ class AverageMeter:
         episode datasets have (logger.py:18-27)."""
         self.benchmark = dataset.benchmark
         self.device = torch.device(device)
-        self.class_ids_interest = torch.tensor(list(dataset.class_ids), dtype=torch.long, device=self.device)
+        ids = list(dataset.class_ids)
+        if self.benchmark == "pascal5i":                     # the PASCAL-5i reader keeps 1-based labels (logger.py:20-22)
+            ids = [i - 1 for i in ids]
+        self.class_ids_interest = torch.tensor(ids, dtype=torch.long, device=self.device)
         self.nclass = NCLASS[self.benchmark]
         self.intersection_buf = torch.zeros(2, self.nclass, dtype=torch.float32, device=self.device)
         self.union_buf = torch.zeros(2, self.nclass, dtype=torch.float32, device=self.device)

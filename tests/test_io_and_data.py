@@ -130,6 +130,67 @@ def test_coco_reader(mods, tmp_path):
     assert torch.equal(b["query_mask"], want) and b["org_query_imsize"] == (40, 30)
 
 
+def test_pascal5i_reader(mods, tmp_path):
+    """PASCAL-5i: fold membership by label, VOC validation list for testing, SBD (MATLAB label maps) + VOC for
+    training with the overlap rules, the 255 band as query_ignore_idx, 1-based class_ids shifted by the meter."""
+    from PIL import Image
+    from scipy.io import savemat
+    _, data = mods
+    rng = np.random.default_rng(5)
+    sbd, voc = tmp_path / "PASCAL5i" / "sbd", tmp_path / "PASCAL5i" / "VOCdevkit" / "VOC2012"
+    for d in (sbd / "img", sbd / "cls", voc / "JPEGImages", voc / "SegmentationClass", voc / "ImageSets" / "Segmentation"):
+        os.makedirs(d)
+
+    def label_map(classes):
+        m = np.zeros((30, 40), dtype=np.uint8)
+        for k, c in enumerate(classes):
+            m[2 + 9 * k: 9 + 9 * k, 5:30] = c
+            m[1 + 9 * k, 5:30] = 255                       # boundary band
+        return m
+
+    voc_val = {"v0": [6, 7], "v1": [6], "v2": [1], "v3": [7, 12], "v4": [6, 10]}      # fold 1 = labels 6..10
+    voc_trn = {"t0": [1, 6], "t1": [2]}
+    sbd_trn = {"s0": [3], "s1": [8], "t1": [4], "v1": [5]}                              # t1 / v1 also in VOC
+    sbd_val = {"s2": [11, 20]}
+    for table, imgdir in ((voc_val, voc / "JPEGImages"), (voc_trn, voc / "JPEGImages"), (sbd_trn, sbd / "img"), (sbd_val, sbd / "img")):
+        _write_images(str(imgdir), [n + ".jpg" for n in table], rng)
+    for table in (voc_val, voc_trn):
+        for n, cs in table.items():
+            Image.fromarray(label_map(cs)).save(voc / "SegmentationClass" / (n + ".png"))
+    for table in (sbd_trn, sbd_val):
+        for n, cs in table.items():
+            savemat(str(sbd / "cls" / (n + ".mat")), {"GTcls": {"Segmentation": label_map(cs)}})
+    (voc / "ImageSets" / "Segmentation" / "val.txt").write_text("\n".join(voc_val) + "\n")
+    (voc / "ImageSets" / "Segmentation" / "train.txt").write_text("\n".join(voc_trn) + "\n")
+    (sbd / "train.txt").write_text("\n".join(sbd_trn) + "\n")
+    (sbd / "val.txt").write_text("\n".join(sbd_val) + "\n")
+
+    data.FSSDataset.initialize(img_size=28, datapath=str(tmp_path), use_original_imgsize=False)
+    np.random.seed(2)
+    ds = data.FSSDataset.build_dataloader("pascal5i", 1, 0, 1, "test", shot=1).dataset
+    assert len(ds) == 1000 and ds.class_ids == [6, 7, 8, 9, 10]
+    assert [os.path.basename(p) for p in ds.images] == ["v0.jpg", "v1.jpg", "v3.jpg", "v4.jpg"]     # v2 holds no fold label
+    assert ds.img_class_map == {0: [6, 7], 1: [6], 2: [7], 3: [6, 10]} and ds.class_img_map[6] == [0, 1, 3] and ds.class_img_map[8] == []
+    b = ds[4 + 1]                                          # wraps to image 1; the class offset stays 0 after the modulo
+    assert os.path.basename(b["query_name"]) == "v1.jpg" and int(b["class_id"]) == 5
+    assert os.path.basename(b["support_names"][0]) in ("v0.jpg", "v4.jpg")
+    lab = torch.nn.functional.interpolate(torch.from_numpy(label_map([6]).astype(np.float32))[None, None], (28, 28), mode="nearest")[0, 0]
+    assert torch.equal(b["query_mask"], (lab == 6).float()) and torch.equal(b["query_ignore_idx"], (lab == 255).float())
+    assert b["support_masks"].shape == (1, 28, 28) and b["support_ignore_idxs"].shape == (1, 28, 28) and b["org_query_imgsize"] == (40, 30)
+    # the class tables were cached beside the data and are read back as plain containers
+    assert os.path.exists(voc / "dataset_1_False.pt")
+    ds2 = data.DatasetPASCAL5i(str(tmp_path), 1, data.EpisodeTransform(28), "test", 1)
+    assert ds2.images == ds.images and ds2.img_class_map == ds.img_class_map and ds2.class_img_map == ds.class_img_map
+    # training: SBD train + val without anything VOC lists, VOC annotation for the rest; labels outside the fold
+    trn = data.DatasetPASCAL5i(str(tmp_path), 1, data.EpisodeTransform(28), "train", 1)
+    assert [os.path.basename(p) for p in trn.images] == ["s0.jpg", "s2.jpg", "t0.jpg", "t1.jpg"]     # s1 holds label 8 only
+    assert trn.targets[0].endswith("s0.mat") and trn.targets[3].endswith("t1.png") and trn.img_class_map[1] == [11, 20]
+    # the meter shifts the 1-based labels to the 0-based class_id of the batches
+    logger = importlib.import_module(mods[0].__name__.rsplit(".", 1)[0] + ".mars.utils.logger")
+    meter = logger.AverageMeter(ds, device="cpu")
+    assert meter.class_ids_interest.tolist() == [5, 6, 7, 8, 9] and meter.nclass == 20
+
+
 def test_synthetic_dataset(mods):
     _, data = mods
     ds = data.DatasetSynthetic(3, 126, 2, 5, fold=2)
