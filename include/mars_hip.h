@@ -241,6 +241,10 @@ int marship_threshold_masks(const float* in, float thr, float* out, int64_t n, v
  * host pointers; keep receives the surviving indices by decreasing score. */
 int marshost_box_nms(const float* boxes, const float* scores, int n, float iou_threshold, int32_t* keep,
                      int32_t* nkeep);
+/* segment_anything/utils/amg.py:274-298 remove_small_regions (there: cv2.connectedComponentsWithStats, 8-connected),
+ * in place on a {0,1} byte mask [h, w].  holes != 0 fills background components smaller than area_thresh, holes == 0
+ * removes foreground components smaller than it (the largest stays if all are).  *changed = 1 iff any region was. */
+int marshost_remove_small_regions(uint8_t* mask, int h, int w, float area_thresh, int holes, int32_t* changed);
 /* scipy.optimize.linear_sum_assignment as the prompt-sampling stage calls it (matcher/Matcher.py:449-450,
  * 471-472, 364-365, 376): w is a host f32 [n, m] matrix with row stride ld; row_ind / col_ind receive
  * min(n, m) pairs ordered by row.  Returns the pair count, negative on error (non-finite entries). */

@@ -77,6 +77,7 @@ _SIGNATURES = {
     "marship_mask_stats": [_P, _I, _I, _I, _F, _F, _P, _P],
     "marship_threshold_masks": [_P, _F, _P, _L, _P],
     "marshost_box_nms": [_P, _P, _I, _F, _P, _P],
+    "marshost_remove_small_regions": [_P, _I, _I, _F, _I, _P],
     "marshost_lap": [_P, _L, _I, _I, _I, _P, _P],
     "marship_pack_masks": [_P, _I, _L, _P, _P],
     "marship_unpack_masks": [_P, _I, _L, _P, _P],

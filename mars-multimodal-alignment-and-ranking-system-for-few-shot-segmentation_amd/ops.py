@@ -559,6 +559,20 @@ def box_nms_host(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float
     return keep[: cnt.value].long()
 
 
+def remove_small_regions_host(mask, area_thresh: float, mode: str):
+    """remove_small_regions (segment_anything/utils/amg.py:274-298) on one host [H, W] bool array:
+    (new mask, changed)."""
+    import numpy as np
+    assert mode in ("holes", "islands")
+    m = np.ascontiguousarray(np.asarray(mask) != 0).astype(np.uint8)
+    _req(m.ndim == 2 and m.size > 0, "remove_small_regions: mask must be a non-empty [H, W] array")
+    changed = ctypes.c_int32(0)
+    hip.check(hip.lib().marshost_remove_small_regions(_vp(m.ctypes.data), m.shape[0], m.shape[1], float(area_thresh),
+                                                      1 if mode == "holes" else 0, ctypes.byref(changed)),
+              "marshost_remove_small_regions")
+    return m.astype(bool), bool(changed.value)
+
+
 def lap_host(weights: torch.Tensor, maximize: bool = False):
     """Rectangular linear assignment on a host f32 matrix: (row_ind, col_ind) int64, min(n, m) pairs by row."""
     w = weights.detach().cpu().float()

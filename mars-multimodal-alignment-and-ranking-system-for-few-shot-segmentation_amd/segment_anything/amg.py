@@ -75,3 +75,62 @@ def rle_to_mask(rle: Dict[str, Any]) -> np.ndarray:
 
 def area_from_rle(rle: Dict[str, Any]) -> int:
     return sum(rle["counts"][1::2])
+
+
+def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str) -> Tuple[np.ndarray, bool]:
+    """amg.py:274-298: fill holes / drop islands smaller than ``area_thresh`` (8-connected); the host routine of the
+    library stands in for cv2.connectedComponentsWithStats."""
+    from .. import ops
+    return ops.remove_small_regions_host(mask, area_thresh, mode)
+
+
+def batched_mask_to_box(masks: np.ndarray) -> np.ndarray:
+    """amg.py:310-353 for host masks [N, H, W]: inclusive XYXY boxes, [0, 0, 0, 0] for an empty mask."""
+    masks = np.asarray(masks, dtype=bool)
+    out = np.zeros((masks.shape[0], 4), dtype=np.float32)
+    for i, m in enumerate(masks):
+        ys, xs = np.flatnonzero(m.any(axis=1)), np.flatnonzero(m.any(axis=0))
+        if ys.size:
+            out[i] = (xs[0], ys[0], xs[-1], ys[-1])
+    return out
+
+
+def coco_encode_rle(uncompressed_rle: Dict[str, Any]) -> Dict[str, Any]:
+    """amg.py:301-308: the run lengths as the COCO API's compressed string (there: pycocotools ``frPyObjects``).
+    Each count from the fourth on is stored as its difference to the count two places back; a value is cut into
+    5-bit groups, low group first, bit 5 says that more groups follow, bit 4 of the last group is the sign, and
+    every group is written as the character with code 48 + group."""
+    counts = [int(c) for c in uncompressed_rle["counts"]]
+    chars = []
+    for i, x in enumerate(counts):
+        if i > 2:
+            x -= counts[i - 2]
+        more = True
+        while more:
+            c = x & 0x1F
+            x >>= 5                                          # arithmetic shift: -1 stays -1
+            more = (x != -1) if (c & 0x10) else (x != 0)
+            if more:
+                c |= 0x20
+            chars.append(chr(c + 48))
+    h, w = uncompressed_rle["size"]
+    return {"size": [h, w], "counts": "".join(chars)}
+
+
+def coco_decode_rle(rle: Dict[str, Any]) -> Dict[str, Any]:
+    """Inverse of ``coco_encode_rle`` (the COCO API's ``rleFrString``): back to uncompressed run lengths."""
+    s, counts, p = rle["counts"], [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    return {"size": list(rle["size"]), "counts": counts}

@@ -17,8 +17,8 @@ import numpy as np
 import torch
 
 from .. import ops
-from .amg import (area_from_rle, build_all_layer_point_grids, build_point_grid, generate_crop_boxes, is_box_near_crop_edge,  # noqa: F401
-                  mask_to_rle)
+from .amg import (area_from_rle, batched_mask_to_box, build_all_layer_point_grids, build_point_grid, coco_encode_rle,  # noqa: F401
+                  generate_crop_boxes, is_box_near_crop_edge, mask_to_rle, remove_small_regions)
 from .modeling import Sam
 from .predictor import SamPredictor
 
@@ -33,8 +33,7 @@ class SamAutomaticMaskGenerator:
                  output_layer: int = -1, sel_output_layer: int = -1, dense_pred: bool = True, **unused):
         assert (points_per_side is None) != (point_grids is None), "Exactly one of points_per_side or point_grid must be provided."
         assert output_mode in ("binary_mask", "uncompressed_rle", "coco_rle"), f"Unknown output_mode {output_mode}."
-        if min_mask_region_area != 0 or output_mode == "coco_rle":
-            raise NotImplementedError("small-region post-processing needs opencv and coco_rle needs pycocotools; neither is built")
+        self.min_mask_region_area = min_mask_region_area
         self.point_grids = (build_all_layer_point_grids(points_per_side, crop_n_layers, crop_n_points_downscale_factor)
                             if points_per_side is not None else point_grids)
         self.crop_n_layers, self.crop_nms_thresh, self.crop_overlap_ratio = crop_n_layers, crop_nms_thresh, crop_overlap_ratio
@@ -196,16 +195,47 @@ class SamAutomaticMaskGenerator:
         out["size"] = (oh, ow)
         return out
 
+    def postprocess_small_regions(self, r: dict, masks_h: np.ndarray, min_area: int, nms_thresh: float):
+        """Lines 559-607: holes, then islands, below ``min_area`` are removed from every mask; boxes are recomputed and
+        a box NMS that prefers untouched masks drops the duplicates this creates.  Only masks that changed take their
+        new pixels and box.  Returns the filtered result and host masks."""
+        n = masks_h.shape[0]
+        if n == 0:
+            return r, masks_h
+        new_masks, scores = [], []
+        for m in masks_h:
+            m1, ch1 = remove_small_regions(m, min_area, "holes")
+            m2, ch2 = remove_small_regions(m1, min_area, "islands")
+            new_masks.append(m2)
+            scores.append(float(not (ch1 or ch2)))
+        new_masks = np.stack(new_masks)
+        boxes = torch.from_numpy(batched_mask_to_box(new_masks))
+        keep = ops.box_nms_host(boxes, torch.tensor(scores), nms_thresh)
+        out_masks, out_boxes = masks_h.copy(), r["boxes"].clone().float()
+        for i in keep.tolist():
+            if scores[i] == 0.0:
+                out_masks[i], out_boxes[i] = new_masks[i], boxes[i]
+        pts = r["points"]
+        out = {k: (v[keep.to(v.device)] if torch.is_tensor(v) else v) for k, v in r.items() if k not in ("points", "boxes", "masks")}
+        out["boxes"], out["points"] = out_boxes[keep], [pts[i] for i in keep.tolist()]
+        out["masks"] = None                                   # the host masks below are the current ones
+        return out, out_masks[keep.numpy()]
+
     def generate(self, image: np.ndarray, select_point_coords=None, select_point_labels=None, select_box=None,
                  select_mask_input=None) -> List[Dict[str, Any]]:
         r = self._run(image, select_point_coords, select_point_labels, select_box, select_mask_input)
         oh, ow = r["size"]
         recs = []
         masks_h = r["masks"].cpu().numpy() > 0 if len(r["iou"]) else np.zeros((0, oh, ow), bool)
+        if self.min_mask_region_area > 0:
+            r, masks_h = self.postprocess_small_regions(r, masks_h, self.min_mask_region_area,
+                                                        max(self.box_nms_thresh, self.crop_nms_thresh))
         for i in range(len(r["iou"])):
             x0, y0, x1, y1 = [float(v) for v in r["boxes"][i].tolist()]
             c0, c1, c2, c3 = [float(v) for v in r["crop_boxes"][i].tolist()]
             seg = masks_h[i] if self.output_mode == "binary_mask" else mask_to_rle(masks_h[i])
+            if self.output_mode == "coco_rle":
+                seg = coco_encode_rle(seg)
             recs.append({"segmentation": seg, "area": int(masks_h[i].sum()), "bbox": [x0, y0, x1 - x0, y1 - y0],
                          "predicted_iou": float(r["iou"][i]), "point_coords": r["points"][i],
                          "low_res_masks": r["low"][i].cpu().numpy(), "stability_score": float(r["stab"][i]),

@@ -318,3 +318,45 @@ def test_generator_with_crop_layers_and_rle(pkg):
         assert ma.shape == img.shape[:2] and float((ma != mb).mean()) < 2e-3
         assert a["area"] == amg.area_from_rle(a["segmentation"])
         assert np.abs(np.array(a["bbox"]) - np.array(b["bbox"])).max() <= 1
+
+
+def test_generator_small_regions_and_coco_rle(pkg):
+    """min_mask_region_area (holes and islands below the area removed, boxes recomputed, NMS preferring untouched masks)
+    and the compressed COCO run-length output, against the same post-processing applied to the plain run's records."""
+    from scipy import ndimage
+    sa = pkg.segment_anything
+    amg = sa.amg
+    cfg = pkg.synth.SAM_ARCHS["tiny"]
+    sd = pkg.synth.sam_state_dict(cfg, seed=5)
+    sam = sa.sam_model_registry["tiny"](state_dict=sd, device="cuda")
+    sam.mask_threshold = 0.5
+    img = np.random.default_rng(3).integers(0, 256, size=(240, 320, 3), dtype=np.uint8)
+    kw = dict(points_per_side=4, points_per_batch=7, pred_iou_thresh=-10.0, stability_score_thresh=0.0, box_nms_thresh=0.9)
+    plain = sa.SamAutomaticMaskGenerator(sam, **kw).generate(img)
+    area = 60
+    recs = sa.SamAutomaticMaskGenerator(sam, min_mask_region_area=area, output_mode="coco_rle", **kw).generate(img)
+    assert 1 <= len(recs) <= len(plain)
+    # the reference's procedure on the plain records (automatic_mask_generator.py:559-607)
+    new, scores = [], []
+    for r in plain:
+        m1, c1 = amg.remove_small_regions(r["segmentation"], area, "holes")
+        m2, c2 = amg.remove_small_regions(m1, area, "islands")
+        new.append(m2)
+        scores.append(float(not (c1 or c2)))
+    assert 0.0 in scores, "the case must exercise a changed mask"
+    boxes = torch.from_numpy(amg.batched_mask_to_box(np.stack(new)))
+    keep = pkg.ops.box_nms_host(boxes, torch.tensor(scores), 0.9).tolist()
+    assert len(keep) == len(recs)
+    eight = np.ones((3, 3), int)
+    for a, i in zip(recs, keep):
+        m = amg.rle_to_mask(amg.coco_decode_rle(a["segmentation"]))
+        want = new[i] if scores[i] == 0.0 else plain[i]["segmentation"]
+        assert np.array_equal(m, want) and a["area"] == int(want.sum()) and a["point_coords"] == plain[i]["point_coords"]
+        if scores[i] == 0.0:
+            x0, y0, x1, y1 = boxes[i].tolist()
+            assert a["bbox"] == [x0, y0, x1 - x0, y1 - y0]
+            lab, n = ndimage.label(m, structure=eight)
+            sizes = np.bincount(lab.reshape(-1))[1:]
+            assert n == 1 or sizes.min() >= area               # no island below the area is left (one may stay if all were)
+        else:
+            assert a["bbox"] == plain[i]["bbox"]

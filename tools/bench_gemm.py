@@ -41,7 +41,7 @@ def run(shape, variant, a, b, out, bias, res):
     kw = {}
     if epi in ("bias", "gelu", "res"):
         kw["bias"] = bias
-    if epi == "gelu":
+    if epi == "gelu" and not os.environ.get("NOACT"):
         kw["act"] = 2
     if epi == "res":
         kw["residual"] = out
@@ -60,14 +60,14 @@ for shape in SHAPES:
     ref = a[:300].float() @ b.float().t() + (bias if epi != "f32" else 0)
     if epi == "f32":
         bias = None
-    if epi == "gelu":
+    if epi == "gelu" and not os.environ.get("NOACT"):
         ref = ref * torch.sigmoid(1.702 * ref)
     for v in VARIANTS:
         out = torch.zeros(M, N, device=dev, dtype=odt)
         run(shape, v, a, b, out, bias, None)
         err = float((out[:300].float() - ref).abs().max())
         last = a[-1:].float() @ b.float().t() + (bias if bias is not None else 0)
-        if epi == "gelu":
+        if epi == "gelu" and not os.environ.get("NOACT"):
             last = last * torch.sigmoid(1.702 * last)
         tail = float((out[-1].float() - last[0]).abs().max())
         assert err < 0.06 and tail < 0.06, (name, v, err, tail)
