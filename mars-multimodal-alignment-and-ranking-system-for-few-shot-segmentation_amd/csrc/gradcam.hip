@@ -109,25 +109,62 @@ __global__ __launch_bounds__(1024) void col_mean_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void cam_head_kernel(const float* __restrict__ f, const float* __restrict__ proj,
                                                         const float* __restrict__ text, int D, int E, float ls,
                                                         float* __restrict__ logits, float* __restrict__ df) {
-    __shared__ float g[1024], dg[1024];
+    __shared__ __attribute__((aligned(16))) float g[1024], dg[1024];
     __shared__ float sm[16];
     const int t = threadIdx.x;
-    // g = f . proj: column t % E, the rows dealt to the 1024 / E thread groups (row-contiguous, coalesced reads)
-    const int ngrp = 1024 / E > 0 ? 1024 / E : 1;
-    {
+    // g = f . proj.  One workgroup reads the whole matrix, so what counts is bytes in flight: with E a multiple of
+    // four (and at most 1024) a thread takes four columns of every (1024 / (E/4))-th row as 16-byte loads, eight rows
+    // at a time; otherwise column t % E, the rows dealt to the 1024 / E thread groups.
+    const bool vec = (E % 4 == 0) && E <= 1024 && E >= 4 && (1024 % (E / 4) == 0) && (((uintptr_t)proj) % 16 == 0);
+    float ge = 0.f;
+    if (vec) {
+        const int e4n = E / 4, ngrp = 1024 / e4n;
+        const int e4 = t % e4n, grp = t / e4n;
+        float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+        int d = grp;
+        for (; d + 7 * ngrp < D; d += 8 * ngrp) {
+            float4 v[8];
+            float fd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = *(const float4*)(proj + (int64_t)(d + u * ngrp) * E + 4 * e4);
+                fd[u] = f[d + u * ngrp];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                part.x += fd[u] * v[u].x; part.y += fd[u] * v[u].y; part.z += fd[u] * v[u].z; part.w += fd[u] * v[u].w;
+            }
+        }
+        for (; d < D; d += ngrp) {
+            const float4 v = *(const float4*)(proj + (int64_t)d * E + 4 * e4);
+            const float fd = f[d];
+            part.x += fd * v.x; part.y += fd * v.y; part.z += fd * v.z; part.w += fd * v.w;
+        }
+        // column sums over the row groups, a group at a time through dg (E floats)
+        for (int k = 0; k < ngrp; ++k) {
+            if (grp == k) {
+                float* q = dg + 4 * e4;
+                if (k == 0) { q[0] = part.x; q[1] = part.y; q[2] = part.z; q[3] = part.w; }
+                else { q[0] += part.x; q[1] += part.y; q[2] += part.z; q[3] += part.w; }
+            }
+            __syncthreads();
+        }
+        if (t < E) { ge = dg[t]; g[t] = ge; }
+        __syncthreads();
+    } else {
+        const int ngrp = 1024 / E > 0 ? 1024 / E : 1;
         float part = 0.f;
         const int e = t % E, grp = t / E;
         if (grp < ngrp)
             for (int d = grp; d < D; d += ngrp) part += f[d] * proj[(int64_t)d * E + e];
         dg[t] = part;
         __syncthreads();
+        if (t < E) {
+            for (int k = 0; k < ngrp; ++k) ge += dg[k * E + t];
+            g[t] = ge;
+        }
+        __syncthreads();
     }
-    float ge = 0.f;
-    if (t < E) {
-        for (int k = 0; k < ngrp; ++k) ge += dg[k * E + t];
-        g[t] = ge;
-    }
-    __syncthreads();
     const float t0 = t < E ? text[t] : 0.f, t1 = t < E ? text[E + t] : 0.f;
     const float ng = sqrtf(block_reduce_sum(ge * ge, sm));
     const float n0 = sqrtf(block_reduce_sum(t0 * t0, sm));
@@ -146,6 +183,28 @@ __global__ __launch_bounds__(1024) void cam_head_kernel(const float* __restrict_
     __syncthreads();
     // df = proj . dg: one wave per row, lanes along the row
     const int lane = t & 63, wv = t >> 6;
+    if (vec && E <= 1024) {
+        // four rows per wave and pass, 16-byte loads: E/4 <= 256 chunks of a row over the 64 lanes
+        const int e4n = E / 4;
+        for (int d0 = wv * 4; d0 < D; d0 += 64) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane; c < e4n; c += 64) {
+                const float4 w4 = *(const float4*)(dg + 4 * c);
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = d0 + u < D ? *(const float4*)(proj + (int64_t)(d0 + u) * E + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += v[u].x * w4.x + v[u].y * w4.y + v[u].z * w4.z + v[u].w * w4.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float r = wave_sum(s[u]);
+                if (lane == 0 && d0 + u < D) df[d0 + u] = r;
+            }
+        }
+        return;
+    }
     for (int d = wv; d < D; d += 16) {
         float s = 0.f;
         for (int e = lane; e < E; e += 64) s += proj[(int64_t)d * E + e] * dg[e];

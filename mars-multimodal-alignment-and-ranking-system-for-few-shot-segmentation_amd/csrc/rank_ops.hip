@@ -236,10 +236,28 @@ __global__ void resample_axis_kernel(const float* __restrict__ in, int planes, i
         const float* w = wt + (int64_t)o * kmax;
         // the first tap initialises the sum, as the vectorised CPU kernel of ATen does
         float acc = 0.f;
-        for (int k = 0; k < ms; ++k) {
-            float v = src[k * step];
-            if (quant_u8) v = (float)(unsigned char)(v * 255.0f) / 255.0f;
-            acc = k == 0 ? v * w[0] : acc + v * w[k];
+        if (ms <= 8) {
+            // short filters (every resize of the path): all taps requested before the first is used
+            float v[8], wk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = k < ms ? src[k * step] : 0.f;
+                wk[k] = k < ms ? w[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < ms) {
+                    float x = v[k];
+                    if (quant_u8) x = (float)(unsigned char)(x * 255.0f) / 255.0f;
+                    acc = k == 0 ? x * wk[0] : acc + x * wk[k];
+                }
+            }
+        } else {
+            for (int k = 0; k < ms; ++k) {
+                float v = src[k * step];
+                if (quant_u8) v = (float)(unsigned char)(v * 255.0f) / 255.0f;
+                acc = k == 0 ? v * w[0] : acc + v * w[k];
+            }
         }
         st_from_f32<TOUT>(out + i, (acc - shift) / scale);
     }
@@ -278,10 +296,28 @@ __global__ __launch_bounds__(256) void pool_masks_kernel(const float* __restrict
     const int64_t n = blockIdx.x / G;
     const int ys = (gy * S) / G, ye = ((gy + 1) * S + G - 1) / G;
     const float* mp = masks + n * (int64_t)S * S;
-    for (int x = threadIdx.x; x < S; x += blockDim.x) {
-        float m = -INFINITY;
-        for (int y = ys; y < ye; ++y) m = fmaxf(m, mp[(int64_t)y * S + x]);
-        colmax[x] = m;
+    if (S % 2 == 0 && ((uintptr_t)masks) % 8 == 0) {
+        // pairs of columns, the rows of the window sixteen at a time: every load of a pass is requested before
+        // the first maximum is taken
+        for (int x2 = threadIdx.x; x2 < S / 2; x2 += blockDim.x) {
+            float mx = -INFINITY, my = -INFINITY;
+            for (int y0 = ys; y0 < ye; y0 += 16) {
+                float2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    v[u] = y0 + u < ye ? *(const float2*)(mp + (int64_t)(y0 + u) * S + 2 * x2) : make_float2(-INFINITY, -INFINITY);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { mx = fmaxf(mx, v[u].x); my = fmaxf(my, v[u].y); }
+            }
+            colmax[2 * x2] = mx;
+            colmax[2 * x2 + 1] = my;
+        }
+    } else {
+        for (int x = threadIdx.x; x < S; x += blockDim.x) {
+            float m = -INFINITY;
+            for (int y = ys; y < ye; ++y) m = fmaxf(m, mp[(int64_t)y * S + x]);
+            colmax[x] = m;
+        }
     }
     __syncthreads();
     for (int gx = threadIdx.x; gx < G; gx += blockDim.x) {
@@ -306,14 +342,23 @@ __global__ __launch_bounds__(256) void proposal_stats_kernel(const uint8_t* __re
         c = block_reduce_sum(c, sm); a = block_reduce_sum(a, sm); b = block_reduce_sum(b, sm);
         if (threadIdx.x == 0) { cnt[n] = (int)c; svv[n] = a; svt[n] = b; }
     } else {
-        float c = 0.f;
-        for (int j = threadIdx.x; j < P; j += blockDim.x) {
-            int any = 0;
-            for (int k = 0; k < N; ++k) any |= bits[(int64_t)k * P + j];
-            c += any ? 1.f : 0.f;
+        // union of the proposals: one patch per thread, blocks N.. share the patches (integer atomics: exact;
+        // the caller clears *ucnt first)
+        const int j = (blockIdx.x - N) * blockDim.x + threadIdx.x;
+        int any = 0;
+        if (j < P) {
+            int k = 0;
+            for (; k + 8 <= N; k += 8) {
+                uint8_t b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b[u] = bits[(int64_t)(k + u) * P + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) any |= b[u];
+            }
+            for (; k < N; ++k) any |= bits[(int64_t)k * P + j];
         }
-        c = block_reduce_sum(c, sm);
-        if (threadIdx.x == 0) *ucnt = (int)c;
+        const float c = block_reduce_sum(any ? 1.f : 0.f, sm);
+        if (threadIdx.x == 0 && c > 0.f) atomicAdd(ucnt, (int)c);
     }
 }
 
@@ -524,7 +569,8 @@ extern "C" int marship_proposal_stats(const uint8_t* bits, int N, int P, const f
                                       float* sum_vva, float* sum_vta, int32_t* union_cnt, void* stream) {
     MARS_CHECK(bits && vva && vta && cnt && sum_vva && sum_vta && union_cnt, "proposal_stats: null pointer");
     MARS_CHECK(N > 0 && P > 0, "proposal_stats: bad shape");
-    hipLaunchKernelGGL(proposal_stats_kernel, dim3(N + 1), dim3(256), 0, (hipStream_t)stream, bits, N, P, vva, vta, cnt, sum_vva, sum_vta, union_cnt);
+    MARS_CHECK(hipMemsetAsync(union_cnt, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess, "proposal_stats: memset failed");
+    hipLaunchKernelGGL(proposal_stats_kernel, dim3(N + (P + 255) / 256), dim3(256), 0, (hipStream_t)stream, bits, N, P, vva, vta, cnt, sum_vva, sum_vta, union_cnt);
     MARS_LAUNCH_CHECK();
     return 0;
 }
