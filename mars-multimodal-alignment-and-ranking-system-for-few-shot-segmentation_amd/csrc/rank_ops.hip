@@ -102,6 +102,14 @@ __global__ __launch_bounds__(1024) void box_mask_kernel(const float* __restrict_
                     const int ln = ((volatile int*)label)[yy * G + xx];
                     if (ln >= 0 && ln < m) m = ln;
                 }
+            // pointer jumping: a label is the index of a pixel of the same component, whose own label is at
+            // least as small; following it a few times shortens the sweeps from the component's diameter to
+            // about its logarithm and leaves the fixed point (the smallest index of the component) as it is
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int lj = ((volatile int*)label)[m];
+                if (lj >= 0 && lj < m) m = lj;
+            }
             if (m < l) { ((volatile int*)label)[i] = m; changed = 1; }
         }
         if (!__syncthreads_or(changed)) break;
