@@ -665,7 +665,7 @@ extern "C" int marship_cosine_table(const float* feats, int64_t ldf, int N, int 
 extern "C" int marship_iou_counts(const float* pred, const float* gt, const float* ignore, int64_t HW, float* counts,
                                   void* stream) {
     MARS_CHECK(pred && gt && counts && HW > 0, "iou_counts: bad arguments");
-    hipLaunchKernelGGL(iou_counts_kernel, dim3(grid_for(HW, 256, 512)), dim3(256), 0, (hipStream_t)stream, pred, gt, ignore, HW, counts);
+    hipLaunchKernelGGL(iou_counts_kernel, dim3(grid_for(HW, 256, 64)), dim3(256), 0, (hipStream_t)stream, pred, gt, ignore, HW, counts);
     MARS_LAUNCH_CHECK();
     return 0;
 }
