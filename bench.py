@@ -200,7 +200,9 @@ def main():
                        "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}"},
             "miou": float(miou), "fb_iou": float(fb_iou),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(), "kernel": RING_KERNELS.get(dom_variant, f"gemm variant {dom_variant}"),
+                         "traffic": pmc_traffic() if args.dtype == "bf16" and dom_variant == 8 else None,   # counted on that kernel
+                         "kernel": RING_KERNELS.get(dom_variant, f"gemm variant {dom_variant}").replace(
+                             "<bf16,", "<bf16," if args.dtype == "bf16" else "<f32,"),
                          "launches": len(dom), "avg_launch_us": ms * 1e3 / max(len(dom), 1), "sampled_steps": 1,
                          "share_of_step": ms / (elapsed / args.steps * 1e3), "all_gemm": all_gemm},
         }
