@@ -3,6 +3,8 @@ same seeded weights and episodes (CLIP ViT-B/16 @528 with GradCAM and AlphaCLIP 
 
   configs[0]  PASCAL-5i style episodes (an ignore band around the object), 1-shot, DINOv2-S/14 reg4 @518, 16 proposals
   configs[1]  COCO-20i 1-shot, DINOv2-L/14 reg4 @518, 64 proposals (the benchmark's own workload)
+  configs[3]  the LVIS configuration's tower, DINOv2-g/14 reg4 @518 (SwiGLU, 40 blocks, 24 heads), 1-shot; 32 of its 128
+              proposals, so that the oracle's AlphaCLIP batch and transport problems finish in half a minute
 
 (Five shots at this size are left to the small-geometry test of tests/test_gpu_pipeline.py: the oracle's exact
 transport solver needs minutes for 64 problems with five times the supply rows.)
@@ -45,7 +47,7 @@ def cfg0(pkg):
     return _config(pkg, "vit_small", 1, 16)
 
 
-@pytest.mark.parametrize("dino,nshot,nprop", [("vit_small", 1, 16), ("vit_large", 1, 64)])
+@pytest.mark.parametrize("dino,nshot,nprop", [("vit_small", 1, 16), ("vit_large", 1, 64), ("vit_giant2", 1, 32)])
 def test_one_episode_against_oracle(pkg, cuda, cfg0, dino, nshot, nprop):
     cfg0 = cfg0 if dino == "vit_small" else _config(pkg, dino, nshot, nprop)
     mars = cfg0["mars"]
@@ -67,7 +69,8 @@ def test_one_episode_against_oracle(pkg, cuda, cfg0, dino, nshot, nprop):
     # rounding noise of the similarity matrix about a hundredfold.  At DINOv2-L depth the similarities agree to
     # 2.4e-6 and the map to 2.8e-4; the fp32 oracle itself sits 0.9e-6 / 0.8e-4 from its own float64 evaluation.
     # The map is an intermediate: what ranks the proposals (the scores below) stays within 1e-4.
-    tol = dict(vva=TOL if dino == "vit_small" else 5e-4)
+    # With the 40 blocks of DINOv2-g the similarities still agree to 1e-5 and every score to 1e-4; the map moves 2.3e-3.
+    tol = dict(vva={"vit_small": TOL, "vit_large": 5e-4}.get(dino, 5e-3))
     for k, v in dev.items():
         assert v <= tol.get(k, TOL), (k, dev)
     assert inner["similarity"] <= 1e-5 and inner["mean_attn"] <= 1e-6, inner
