@@ -6,8 +6,9 @@ same seeded weights and episodes (CLIP ViT-B/16 @528 with GradCAM and AlphaCLIP 
   configs[3]  the LVIS configuration's tower, DINOv2-g/14 reg4 @518 (SwiGLU, 40 blocks, 24 heads), 1-shot; 32 of its 128
               proposals, so that the oracle's AlphaCLIP batch and transport problems finish in half a minute
 
-(Five shots at this size are left to the small-geometry test of tests/test_gpu_pipeline.py: the oracle's exact
-transport solver needs minutes for 64 problems with five times the supply rows.)
+  configs[2]  COCO-20i 5-shot, DINOv2-L, 8 of its 64 proposals: the oracle's exact transport solver needs minutes for
+              64 problems with five times the supply rows (the small-geometry five-shot test of tests/test_gpu_pipeline.py
+              runs every proposal)
 
 Tolerance (north star): every per-proposal score, the two priors and the EMD within 1e-4, the same rank
 order except among scores closer than 2e-4, the same merged mask, the same intersection / union counts.  The
@@ -47,7 +48,7 @@ def cfg0(pkg):
     return _config(pkg, "vit_small", 1, 16)
 
 
-@pytest.mark.parametrize("dino,nshot,nprop", [("vit_small", 1, 16), ("vit_large", 1, 64), ("vit_giant2", 1, 32)])
+@pytest.mark.parametrize("dino,nshot,nprop", [("vit_small", 1, 16), ("vit_large", 1, 64), ("vit_giant2", 1, 32), ("vit_large", 5, 8)])
 def test_one_episode_against_oracle(pkg, cuda, cfg0, dino, nshot, nprop):
     cfg0 = cfg0 if dino == "vit_small" else _config(pkg, dino, nshot, nprop)
     mars = cfg0["mars"]
