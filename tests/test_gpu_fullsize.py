@@ -105,3 +105,22 @@ def test_fp32_towers_rank_like_bf16(full, pkg):
     tau = conc / (n * (n - 1) / 2)
     print(f"kendall tau bf16 vs fp32 final scores: {tau:.3f}")
     assert tau > 0.8
+
+
+def test_256_proposals(full, pkg):
+    """The proposal budget of the largest configuration (256, bf16 towers): the AlphaCLIP batch runs in chunks, every
+    per-proposal quantity equals what a run on a 64-proposal subset gives for the same proposals (bitwise), the merged
+    mask is the union of the kept proposals and the order sorts the scores."""
+    mars, ep, _ = full
+    big = pkg.synth.make_episode(1000 * bench.FOLD + 2, size=bench.SIZE, nshot=1, nprop=256, fold=bench.FOLD)
+    big = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in big.items()}
+    pred, sc = _run(mars, big, big["mask_proposals"])
+    assert sc["score"].numel() == 256 and bool(torch.isfinite(sc["score"]).all())
+    ordered = sc["score"][sc["order"].long()]
+    assert bool((ordered[:-1] >= ordered[1:]).all())
+    kept = big["mask_proposals"][sc["keep"].bool().cuda()]
+    assert torch.equal(pred, (kept.sum(0) > 0).float())
+    idx = torch.arange(96, 160)                                       # straddles the chunk boundary at 128
+    _, sub = _run(mars, big, big["mask_proposals"][idx.cuda()].contiguous())
+    for k in ("emd", "aclip", "cnt", "svv", "svt"):
+        assert torch.equal(sc[k][idx], sub[k]), k
