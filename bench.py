@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="side measurement: 8-bit float operands in the AlphaCLIP attention (not the headline configuration)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +129,9 @@ def main():
     AverageMeter = import_module(pkg.__name__ + ".mars.utils.logger").AverageMeter
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     sds = state_dicts(pkg)
-    mars = MARS.build_MARS_fss(build_args(dev, dtype), state_dicts=sds)
+    margs = build_args(dev, dtype)
+    margs.fp8_attention = args.fp8_attention
+    mars = MARS.build_MARS_fss(margs, state_dicts=sds)
     Evaluator.initialize()
     dataset = types.SimpleNamespace(benchmark="coco", class_ids=[FOLD + 4 * i for i in range(20)])
     meter = AverageMeter(dataset, device=dev)
@@ -194,7 +198,8 @@ def main():
         out = {
             "metric": "query images/sec", "value": args.steps * world / elapsed, "unit": "query images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype + ("+fp8-attention" if args.fp8_attention else ""), "data": "synthetic",
             "config": {"workload": "COCO-20i fold0 1-shot, DINOv2-L/14-reg4@518 + CLIP ViT-B/16 GradCAM + AlphaCLIP ViT-L/14@336, "
                                    "64 proposals, exact EMD, rank+merge+IoU (BASELINE configs[1])",
                        "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}"},

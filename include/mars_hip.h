@@ -102,6 +102,13 @@ int marship_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dty
  * lse f32 [B*H, T] receives log-sum-exp of the scaled scores (may be NULL). */
 int marship_flash_attn(const void* qkv, void* O, float* lse, int B, int T, int H, int causal,
                        void* stream);
+/* The same attention with q, k, v and the probabilities quantised to 8-bit floats (OCP e4m3, one scale per image,
+ * head and operand) and both contractions on the fp8 MFMA; f32 softmax and accumulation, no mask, no lse.  The caller
+ * brings the workspace: q8, k8 [B*H*Tp*64] bytes, vt8 [B*H*64*Tp] bytes, scales [B*H*3] f32, Tp = T rounded up to 32.
+ * For the configuration that names an fp8 attention path; the reference (attention.py:54-60; alpha_clip/model.py:233-246)
+ * has no such mode. */
+int marship_flash_attn_fp8(const void* qkv, void* O, int B, int T, int H, void* q8, void* k8, void* vt8, float* scales,
+                           int Tp, void* stream);
 /* acc[i,j] += scale * sum_h exp(q_h[i].k_h[j]/8 - lse[h,i]) over the patch block starting at
  * token `off` of image 0 (bf16 qkv as above): the head/layer mean of the attention maps
  * (PriorInformationRefinementModule.py:31-45) without materialising them. */

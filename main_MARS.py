@@ -49,6 +49,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--exp_name", type=str, default="mars")
     p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--fp8_attention", action="store_true",
+                   help="8-bit float (e4m3) operands in the attention of the AlphaCLIP proposal tower (bf16 towers only)")
     # additions of this implementation
     p.add_argument("--class_name", type=str, default="object", help="text retriever stand-in: the class name used in the prompts")
     p.add_argument("--class_description", type=str, default="")

@@ -213,6 +213,9 @@ def build_filtering_and_merging_module(args, state_dict=None):
         backbone_weights_path=getattr(args, "alphaclip_weights", None),
         encoder_kwargs={"device": args.device, "download_root": getattr(args, "models_path", None), "state_dict": state_dict,
                         "dtype": getattr(args, "dtype", torch.float32)})
+    # the proposal tower's attention with 8-bit float operands (bf16 towers only): args.fp8_attention or MARS_FP8_ATTENTION=1
+    if (getattr(args, "fp8_attention", False) or os.environ.get("MARS_FP8_ATTENTION", "0") == "1") and hasattr(model, "vtower"):
+        model.vtower.fp8_attention = True
     return FilteringMergingModule(
         alpha_clip_model=model, img_transforms=transforms[0], mask_transforms=transforms[1], alpha=args.alpha_coverage,
         static_threshold=args.static_threshold, dynamic_threshold=args.dynamic_threshold, device=args.device)

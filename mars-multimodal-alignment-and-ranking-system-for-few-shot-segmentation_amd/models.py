@@ -70,6 +70,7 @@ class Tower:
         self.D, self.H, self.device, self.dtype = D, heads, device, dtype
         self.blocks: List[Block] = []
         self._ws: Dict[Tuple[int, int, int], dict] = {}
+        self.fp8_attention = False            # bf16 towers only: q, k, v and the probabilities as 8-bit floats
 
     # ---- workspaces (allocated once per shape; pads stay zero) ----
     def ws(self, B: int, T: int, hidden: int) -> dict:
@@ -103,6 +104,9 @@ class Tower:
         probabilities of image 0 restricted to tokens off..off+Pn."""
         D, H, Tp = self.D, self.H, w["Tp"]
         use_flash = self.dtype == torch.bfloat16 and flash_enabled() and not need_probs
+        if use_flash and self.fp8_attention and not causal and mean_acc is None:
+            ops.flash_attn_fp8(w["qkv"], w["ao"], B, T, H, w.setdefault("fp8", {}))
+            return None
         if use_flash:
             ops.flash_attn(w["qkv"], w["ao"], w["lse"], B, T, H, causal)
             if mean_acc is not None:

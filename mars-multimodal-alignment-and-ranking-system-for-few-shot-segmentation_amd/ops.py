@@ -217,6 +217,22 @@ def flash_attn(qkv: torch.Tensor, O: torch.Tensor, lse: Optional[torch.Tensor], 
               "marship_flash_attn")
 
 
+def flash_attn_fp8(qkv: torch.Tensor, O: torch.Tensor, B: int, T: int, H: int, ws: dict):
+    """Attention with fp8 (e4m3) operands on packed bf16 qkv.  ``ws`` keeps the quantised operands between calls."""
+    _dev(qkv, O)
+    D = H * 64
+    _req(qkv.dtype == torch.bfloat16 and O.dtype == torch.bfloat16, "flash_attn_fp8: bf16 qkv and output")
+    _req(B * T * 3 * D <= _avail(qkv) and B * T * D <= _avail(O), "flash_attn_fp8: overrun")
+    Tp = (T + 31) // 32 * 32
+    key = (B, T, H)
+    if ws.get("key") != key:
+        n = B * H * Tp * 64
+        ws.update(key=key, q8=torch.zeros(n, dtype=torch.uint8, device=qkv.device), k8=torch.zeros(n, dtype=torch.uint8, device=qkv.device),
+                  vt8=torch.zeros(n, dtype=torch.uint8, device=qkv.device), scales=torch.zeros(B * H * 3, dtype=torch.float32, device=qkv.device))
+    hip.check(hip.lib().marship_flash_attn_fp8(ptr(qkv), ptr(O), B, T, H, ptr(ws["q8"]), ptr(ws["k8"]), ptr(ws["vt8"]), ptr(ws["scales"]),
+                                               Tp, stream()), "marship_flash_attn_fp8")
+
+
 def flash_attn_mean(qkv: torch.Tensor, lse: torch.Tensor, T: int, H: int, off: int, Pn: int, scale: float,
                     acc: torch.Tensor):
     _dev(qkv, lse, acc)

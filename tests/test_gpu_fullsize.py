@@ -124,3 +124,24 @@ def test_256_proposals(full, pkg):
     _, sub = _run(mars, big, big["mask_proposals"][idx.cuda()].contiguous())
     for k in ("emd", "aclip", "cnt", "svv", "svt"):
         assert torch.equal(sc[k][idx], sub[k]), k
+
+
+def test_fp8_attention_ranks_like_bf16(full, pkg):
+    """The fp8-attention configuration (q, k, v and probabilities of the AlphaCLIP tower as e4m3) on the benchmark
+    episode: reported, loosely gated like the fp32 / bf16 comparison - AlphaCLIP features stay close in direction and
+    the final scores rank the proposals nearly alike."""
+    from scipy.stats import kendalltau
+    mars, ep, _ = full
+    tower = mars.filtering_merging_component.alpha_clip_model.vtower
+    _, ref = _run(mars, ep, ep["mask_proposals"])
+    tower.fp8_attention = True
+    try:
+        pred8, sc8 = _run(mars, ep, ep["mask_proposals"])
+    finally:
+        tower.fp8_attention = False
+    cos = torch.nn.functional.cosine_similarity(ref["feats"].float(), sc8["feats"].float(), dim=1)
+    tau = kendalltau(ref["score"].double().numpy(), sc8["score"].double().numpy()).statistic
+    print(f"fp8 attention vs bf16: min feature cosine {float(cos.min()):.4f}, Kendall tau of the scores {tau:.3f}")
+    assert float(cos.min()) > 0.98 and tau > 0.8
+    assert torch.equal(sc8["emd"], ref["emd"]) and torch.equal(sc8["cnt"], ref["cnt"])      # nothing else changes
+    assert set(pred8.unique().tolist()) <= {0.0, 1.0}

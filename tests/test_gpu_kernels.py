@@ -292,6 +292,46 @@ def test_flash_attention_matches_reference(pkg, cuda, B, T, H, causal):
         assert float((acc[:, :Pn] - want).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 70, 2), (2, 577, 3), (1, 33, 2), (1, 1374, 1)])
+def test_fp8_attention_close_to_reference(pkg, cuda, B, T, H):
+    """q, k, v and the probabilities as 8-bit floats (e4m3: three mantissa bits, a relative step of 1/16), f32 softmax
+    and accumulation: the output stays within 15 % of the largest value of the f32 attention at its worst element and 1.5 % on
+    average, no further from it than the same quantisation emulated in torch explains, and a reused workspace holds nothing stale."""
+    D = H * 64
+    qkv = (_rand((B * T, 3 * D), 5, cuda) * 1.5).to(torch.bfloat16)
+    O = torch.full((B * T, D), float("nan"), device=cuda, dtype=torch.bfloat16)
+    ws = {}
+    pkg.ops.flash_attn_fp8(qkv, O, B, T, H, ws)
+    q = qkv.float().view(B, T, 3, H, 64)
+    s = torch.einsum("bthd,bshd->bhts", q[:, :, 0], q[:, :, 1]) * 0.125
+    ref = torch.einsum("bhts,bshd->bthd", s.softmax(-1), q[:, :, 2]).reshape(B * T, D)
+    err = (O.float() - ref).abs()
+    scale = float(ref.abs().max())
+    assert bool(torch.isfinite(O.float()).all())
+    assert float(err.max()) < 0.15 * scale and float(err.mean()) < 0.015 * scale, (float(err.max()), float(err.mean()), scale)
+    # the same quantisation emulated in torch (per image, head and operand: 448 / amax, e4m3; probabilities as
+    # 256 p relative to the row maximum): the kernel's error against the f32 attention is the error this explains
+    f8 = torch.float8_e4m3fn
+    x = q.permute(0, 3, 2, 1, 4)                                      # [B, H, 3, T, 64]
+    amax = x.abs().amax(dim=(3, 4), keepdim=True).clamp_min(1e-20)
+    xq = (x * (448.0 / amax)).to(f8).float() * (amax / 448.0)
+    se = torch.einsum("bhtd,bhsd->bhts", xq[:, :, 0], xq[:, :, 1]) * 0.125
+    pe = torch.exp(se - se.amax(-1, keepdim=True))
+    pq = (pe * 256.0).to(f8).float() / 256.0
+    emu = (torch.einsum("bhts,bhsd->bthd", pq, xq[:, :, 2]) / pe.sum(-1).permute(0, 2, 1)[..., None]).reshape(B * T, D)
+    emu_err = float((emu - ref).abs().mean())
+    assert float(err.mean()) < 1.5 * emu_err + 1e-4, (float(err.mean()), emu_err)
+    assert float((O.float() - emu).abs().mean()) < 1.5 * emu_err + 2e-3 * scale
+    # a second call through the same workspace with other data gives that data's result (nothing stale is read)
+    qkv2 = (_rand((B * T, 3 * D), 6, cuda) * 0.7).to(torch.bfloat16)
+    O2 = torch.empty_like(O)
+    pkg.ops.flash_attn_fp8(qkv2, O2, B, T, H, ws)
+    q2 = qkv2.float().view(B, T, 3, H, 64)
+    s2 = torch.einsum("bthd,bshd->bhts", q2[:, :, 0], q2[:, :, 1]) * 0.125
+    ref2 = torch.einsum("bhts,bshd->bthd", s2.softmax(-1), q2[:, :, 2]).reshape(B * T, D)
+    assert float((O2.float() - ref2).abs().max()) < 0.15 * float(ref2.abs().max())
+
+
 def test_flash_attention_spiked_scores(pkg, cuda):
     """A key that dominates a row late in the sequence forces the online-softmax rescale."""
     T, H = 200, 1
