@@ -16,7 +16,34 @@
 namespace {
 
 constexpr float FP8_MAX = 448.0f;
-constexpr float P_SCALE = 256.0f;            // probabilities are stored as 256 p: keeps small ones out of the subnormals
+// probabilities are stored as 256 p (<= 256 < 448): keeps small ones out of the subnormals
+
+// maximum / sum over the four lanes that share lane % 16 (the four key groups of one query), on the gfx950 row and
+// half-wave swaps instead of two trips through the LDS crossbar
+// (written out: the compiler folds the builtin's pair of results into one when both operands hold the same value;
+// the two wait states cover the swap's read of registers a VALU instruction has just written)
+__device__ __forceinline__ void swap_rows16(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_halves32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float group4_max(float x) {
+    float a = x, b = x;
+    swap_rows16(a, b);                        // a = rows [0, 0, 2, 2], b = rows [1, 1, 3, 3]
+    a = fmaxf(a, b);
+    b = a;
+    swap_halves32(a, b);                      // a = halves [lo, lo], b = [hi, hi]
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float group4_sum(float x) {
+    float a = x, b = x;
+    swap_rows16(a, b);
+    a = a + b;
+    b = a;
+    swap_halves32(a, b);
+    return a + b;
+}
 
 __device__ __forceinline__ float clamp8(float v) { return fminf(fmaxf(v, -FP8_MAX), FP8_MAX); }
 
@@ -138,7 +165,8 @@ __global__ __launch_bounds__(256) void flash_attn_fp8_kernel(const uint8_t* __re
         for (int c = 0; c < QB; ++c) {
             // scores of 32 keys: two 16-key halves, each two MFMAs over the 64 dims; this lane gets keys
             // k0 + 16 hb + 4 g + r of query q0 + 16 c + i
-            float sv8[8];
+            // raw accumulators z; the score in the exp2 domain is z * sc (sc > 0, so maxima can be taken on z)
+            float z8[8];
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -146,48 +174,49 @@ __global__ __launch_bounds__(256) void flash_attn_fp8_kernel(const uint8_t* __re
                 z = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(cur.k[hb][1], qf[c][1], z, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = z[r] * sc;
+                    float v = z[r];
                     if (edge && k0 + 16 * hb + 4 * g + r >= T) v = -INFINITY;
-                    sv8[4 * hb + r] = v;
+                    z8[4 * hb + r] = v;
                 }
             }
-            float mloc = fmaxf(fmaxf(fmaxf(sv8[0], sv8[1]), fmaxf(sv8[2], sv8[3])), fmaxf(fmaxf(sv8[4], sv8[5]), fmaxf(sv8[6], sv8[7])));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run[c], mloc);     // finite: every tile holds at least one key below T
-            const float alpha = __builtin_amdgcn_exp2f(m_run[c] - m_new);
-            m_run[c] = m_new;
+            float mloc = fmaxf(fmaxf(fmaxf(z8[0], z8[1]), fmaxf(z8[2], z8[3])), fmaxf(fmaxf(z8[4], z8[5]), fmaxf(z8[6], z8[7])));
+            mloc = group4_max(mloc);
+            const float m_new = fmaxf(m_run[c], mloc * sc);     // finite: every tile holds at least one key below T
+            if (__any(m_new != m_run[c])) {                     // the running maximum moved for some query of the block
+                const float alpha = __builtin_amdgcn_exp2f(m_run[c] - m_new);
+                l_run[c] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[c][d] *= alpha;
+                m_run[c] = m_new;
+            }
+            // probabilities as 256 p = exp2(z sc - (m - 8)): one fused multiply-add and one exponential per score
+            const float off = 8.0f - m_new;
             float p[8], psum = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                p[j] = __builtin_amdgcn_exp2f(sv8[j] - m_new);
+                p[j] = __builtin_amdgcn_exp2f(fmaf(z8[j], sc, off));
                 psum += p[j];
             }
-            l_run[c] = l_run[c] * alpha + psum;            // partial over this lane's keys; joined over g at the end
+            l_run[c] += psum;                               // 256 x the partial row sum over this lane's keys
             // B operand of O^T = V^T P^T: slots 0..3 = keys 4g..4g+3 of the first half, 4..7 = the same of the second
             // (256 p <= 256 < 448: no clamp needed)
             int wlo = 0, whi = 0;
-            wlo = __builtin_amdgcn_cvt_pk_fp8_f32(p[0] * P_SCALE, p[1] * P_SCALE, wlo, false);
-            wlo = __builtin_amdgcn_cvt_pk_fp8_f32(p[2] * P_SCALE, p[3] * P_SCALE, wlo, true);
-            whi = __builtin_amdgcn_cvt_pk_fp8_f32(p[4] * P_SCALE, p[5] * P_SCALE, whi, false);
-            whi = __builtin_amdgcn_cvt_pk_fp8_f32(p[6] * P_SCALE, p[7] * P_SCALE, whi, true);
+            wlo = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], wlo, false);
+            wlo = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], wlo, true);
+            whi = __builtin_amdgcn_cvt_pk_fp8_f32(p[4], p[5], whi, false);
+            whi = __builtin_amdgcn_cvt_pk_fp8_f32(p[6], p[7], whi, true);
             const long pf = (long)(((uint64_t)(uint32_t)whi << 32) | (uint32_t)wlo);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                acc[c][d] *= alpha;
-                acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(cur.v[d], pf, acc[c][d], 0, 0, 0);
-            }
+            for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(cur.v[d], pf, acc[c][d], 0, 0, 0);
         }
         cur = nxt;
     }
 #pragma unroll
     for (int c = 0; c < QB; ++c) {
-        float l = l_run[c];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = group4_sum(l_run[c]);
         const int q = q0 + 16 * c + i;
         if (q < T) {
-            const float f = sv / (P_SCALE * l);
+            const float f = sv / l;                            // l and the accumulators both carry the factor 256
             __bf16* op = O + ((int64_t)b * T + q) * (H * 64) + h * 64 + 4 * g;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
