@@ -295,7 +295,10 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const __bf16* __
 __global__ __launch_bounds__(256) void flash_attn_mean_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ lse,
                                                               int T, int H, int off, int Pn, float scale_out,
                                                               float* __restrict__ acc_out, int64_t ldacc) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[KT * ROWB];
+    // the K tile, the query fragments and the log-sum-exp of head h + 1 are requested before head h is worked on
+    // (two LDS buffers, one barrier per head): a head is 8 MFMAs and 16 exponentials per lane, far less than a
+    // trip to memory
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][KT * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
     const int D = H * 64;
@@ -304,33 +307,54 @@ __global__ __launch_bounds__(256) void flash_attn_mean_kernel(const __bf16* __re
     const int myi = i0 + r16;
     const int qrow = off + min(myi, Pn - 1);
     const unsigned char* base = (const unsigned char*)qkv;
+    constexpr float LOG2E = 1.44269504088896340736f;
     f32x4 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int h = 0; h < H; ++h) {
+    int kr[2], kc[2];
+    int64_t koff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int qd = tid + 256 * i;
+        kr[i] = qd >> 3;
+        kc[i] = qd & 7;
+        koff[i] = (int64_t)D * 2 + (int64_t)(off + min(j0 + kr[i], Pn - 1)) * row_b + kc[i] * 16;
+    }
+    uint4 kreg[2], qreg[2];
+    float lreg;
+    auto fetch = [&](int h) {
         const unsigned char* hb = base + (int64_t)h * 128;
         const unsigned char* qp = hb + (int64_t)qrow * row_b;
-        const bf16x8 qf0 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 16 * g));
-        const bf16x8 qf1 = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 + 16 * g));
-        const float l = lse[(int64_t)h * T + qrow];
-        __syncthreads();  // previous head's reads of the K tile are done
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int qd = tid + 256 * i, r = qd >> 3, c = qd & 7;
-            const int key = off + min(j0 + r, Pn - 1);
-            *(uint4*)(&lds[tile_off(r, c)]) = *(const uint4*)(hb + (int64_t)D * 2 + (int64_t)key * row_b + c * 16);
-        }
-        __syncthreads();
+        qreg[0] = *(const uint4*)(qp + 16 * g);
+        qreg[1] = *(const uint4*)(qp + 64 + 16 * g);
+        lreg = lse[(int64_t)h * T + qrow] * LOG2E;
+        kreg[0] = *(const uint4*)(hb + koff[0]);
+        kreg[1] = *(const uint4*)(hb + koff[1]);
+    };
+    fetch(0);
+    *(uint4*)(&lds[0][tile_off(kr[0], kc[0])]) = kreg[0];
+    *(uint4*)(&lds[0][tile_off(kr[1], kc[1])]) = kreg[1];
+    __syncthreads();
+    for (int h = 0; h < H; ++h) {
+        const bf16x8 qf0 = __builtin_bit_cast(bf16x8, qreg[0]), qf1 = __builtin_bit_cast(bf16x8, qreg[1]);
+        const float l = lreg;
+        if (h + 1 < H) fetch(h + 1);
+        const unsigned char* kt = lds[h & 1];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *(const uint4*)(lds + tile_off(16 * f + r16, g)));
-            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *(const uint4*)(lds + tile_off(16 * f + r16, 4 + g)));
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *(const uint4*)(kt + tile_off(16 * f + r16, g)));
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *(const uint4*)(kt + tile_off(16 * f + r16, 4 + g)));
             f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, s, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[f][j] += expf(s[j] * 0.125f - l);
+            for (int j = 0; j < 4; ++j) acc[f][j] += __builtin_amdgcn_exp2f(fmaf(s[j], 0.125f * LOG2E, -l));
         }
+        if (h + 1 < H) {
+            *(uint4*)(&lds[(h + 1) & 1][tile_off(kr[0], kc[0])]) = kreg[0];
+            *(uint4*)(&lds[(h + 1) & 1][tile_off(kr[1], kc[1])]) = kreg[1];
+        }
+        __syncthreads();   // the next head's tile is in place; everybody is done with this one before it is overwritten
     }
     if (myi < Pn) {
 #pragma unroll
