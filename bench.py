@@ -93,7 +93,9 @@ def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 counter passes (FETCH_SIZE and
     WRITE_SIZE, separate runs, FETCH_SIZE doubled for gfx950; see tools/pmc_traffic.py), or None."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):   # newest tag first
+    import re
+    tag = lambda p: [int(x) for x in re.findall(r"\d+", os.path.basename(p))]     # r1_v10 after r1_v9  # noqa: E731
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=tag, reverse=True):   # newest tag first
         try:
             return float(json.load(open(path))["bytes_per_launch"])
         except (OSError, KeyError, ValueError):
