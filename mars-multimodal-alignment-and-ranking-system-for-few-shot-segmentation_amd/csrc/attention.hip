@@ -320,25 +320,28 @@ __global__ __launch_bounds__(256) void flash_attn_mean_kernel(const __bf16* __re
         kc[i] = qd & 7;
         koff[i] = (int64_t)D * 2 + (int64_t)(off + min(j0 + kr[i], Pn - 1)) * row_b + kc[i] * 16;
     }
-    uint4 kreg[2], qreg[2];
+    // (plain variables and a macro: behind a lambda the compiler keeps the fetched registers in scratch memory and
+    // waits for the loads at once)
+    uint4 kreg0, kreg1, qreg0, qreg1;
     float lreg;
-    auto fetch = [&](int h) {
-        const unsigned char* hb = base + (int64_t)h * 128;
-        const unsigned char* qp = hb + (int64_t)qrow * row_b;
-        qreg[0] = *(const uint4*)(qp + 16 * g);
-        qreg[1] = *(const uint4*)(qp + 64 + 16 * g);
-        lreg = lse[(int64_t)h * T + qrow] * LOG2E;
-        kreg[0] = *(const uint4*)(hb + koff[0]);
-        kreg[1] = *(const uint4*)(hb + koff[1]);
-    };
-    fetch(0);
-    *(uint4*)(&lds[0][tile_off(kr[0], kc[0])]) = kreg[0];
-    *(uint4*)(&lds[0][tile_off(kr[1], kc[1])]) = kreg[1];
+#define MARS_FETCH_HEAD(h_)                                                   \
+    {                                                                         \
+        const unsigned char* hb_ = base + (int64_t)(h_) * 128;                \
+        const unsigned char* qp_ = hb_ + (int64_t)qrow * row_b;               \
+        qreg0 = *(const uint4*)(qp_ + 16 * g);                                \
+        qreg1 = *(const uint4*)(qp_ + 64 + 16 * g);                           \
+        lreg = lse[(int64_t)(h_) * T + qrow];                                 \
+        kreg0 = *(const uint4*)(hb_ + koff[0]);                               \
+        kreg1 = *(const uint4*)(hb_ + koff[1]);                               \
+    }
+    MARS_FETCH_HEAD(0)
+    *(uint4*)(&lds[0][tile_off(kr[0], kc[0])]) = kreg0;
+    *(uint4*)(&lds[0][tile_off(kr[1], kc[1])]) = kreg1;
     __syncthreads();
     for (int h = 0; h < H; ++h) {
-        const bf16x8 qf0 = __builtin_bit_cast(bf16x8, qreg[0]), qf1 = __builtin_bit_cast(bf16x8, qreg[1]);
-        const float l = lreg;
-        if (h + 1 < H) fetch(h + 1);
+        const bf16x8 qf0 = __builtin_bit_cast(bf16x8, qreg0), qf1 = __builtin_bit_cast(bf16x8, qreg1);
+        const float l = lreg * LOG2E;
+        if (h + 1 < H) MARS_FETCH_HEAD(h + 1)
         const unsigned char* kt = lds[h & 1];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
@@ -351,11 +354,12 @@ __global__ __launch_bounds__(256) void flash_attn_mean_kernel(const __bf16* __re
             for (int j = 0; j < 4; ++j) acc[f][j] += __builtin_amdgcn_exp2f(fmaf(s[j], 0.125f * LOG2E, -l));
         }
         if (h + 1 < H) {
-            *(uint4*)(&lds[(h + 1) & 1][tile_off(kr[0], kc[0])]) = kreg[0];
-            *(uint4*)(&lds[(h + 1) & 1][tile_off(kr[1], kc[1])]) = kreg[1];
+            *(uint4*)(&lds[(h + 1) & 1][tile_off(kr[0], kc[0])]) = kreg0;
+            *(uint4*)(&lds[(h + 1) & 1][tile_off(kr[1], kc[1])]) = kreg1;
         }
         __syncthreads();   // the next head's tile is in place; everybody is done with this one before it is overwritten
     }
+#undef MARS_FETCH_HEAD
     if (myi < Pn) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
