@@ -27,7 +27,7 @@ def build_parser() -> argparse.ArgumentParser:
     p = argparse.ArgumentParser(description="MARS few-shot segmentation test loop (MI355X path)")
     p.add_argument("--dataset_path", type=str, default=None)
     p.add_argument("--mask_proposals_path", type=str, default=None)
-    p.add_argument("--benchmark", type=str, default="coco", choices=["fss", "coco", "pascal5i"])
+    p.add_argument("--benchmark", type=str, default="coco", choices=["fss", "coco", "pascal5i", "lvis"])
     p.add_argument("--nworker", type=int, default=0)
     p.add_argument("--nshot", type=int, default=1)
     p.add_argument("--fold", type=int, default=0)

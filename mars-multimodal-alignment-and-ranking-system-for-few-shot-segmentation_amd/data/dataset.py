@@ -3,11 +3,11 @@ from __future__ import annotations
 
 from torch.utils.data import DataLoader
 
-from .episodes import DatasetCOCO, DatasetFSS, DatasetPASCAL5i, EpisodeTransform
+from .episodes import DatasetCOCO, DatasetFSS, DatasetLVIS, DatasetPASCAL5i, EpisodeTransform
 
 
 class FSSDataset:
-    datasets = {"coco": DatasetCOCO, "fss": DatasetFSS, "pascal5i": DatasetPASCAL5i}
+    datasets = {"coco": DatasetCOCO, "fss": DatasetFSS, "pascal5i": DatasetPASCAL5i, "lvis": DatasetLVIS}
 
     @classmethod
     def initialize(cls, img_size, datapath, use_original_imgsize):

@@ -1,6 +1,6 @@
 """Few-shot episode datasets: the reference's batch dictionary (query_img [3, S, S] in [0, 1], query_mask [S, S],
 support_imgs [ns, 3, S, S], support_masks [ns, S, S], class_id, names) for FSS-1000
-(/root/reference/matcher/data/fss.py), COCO-20i (coco.py), PASCAL-5i (pascal5i.py) and seeded synthetic episodes.
+(/root/reference/matcher/data/fss.py), COCO-20i (coco.py), PASCAL-5i (pascal5i.py), LVIS-92i (lvis.py) and seeded synthetic episodes.
 
 The image transform is the reference's ``Resize((S, S))`` + ``ToTensor()`` (dataset.py:32-35) on Pillow images:
 bilinear with antialiasing, then /255.  Masks are resized with nearest-neighbour sampling (fss.py:38, coco.py:47).
@@ -221,6 +221,146 @@ class DatasetPASCAL5i(torch.utils.data.Dataset):
                 "org_query_imgsize": q_pil.size, "support_imgs": torch.stack([tr(Image.open(s)) for s in support]),
                 "support_masks": torch.stack([m for m, _ in s_pairs]), "support_names": support,
                 "support_ignore_idxs": torch.stack([g for _, g in s_pairs]), "class_id": torch.tensor(c)}
+
+
+def polygon_to_mask(xy, h: int, w: int) -> np.ndarray:
+    """One polygon (x0, y0, x1, y1, ...) -> [h, w] bool, the COCO API's ``rleFrPoly`` restated (the reference reaches
+    it through detectron2's ``polygons_to_bitmask`` -> pycocotools ``frPyObjects``, /root/reference/matcher/data/
+    lvis.py:99-105): the outline is drawn at five times the resolution with one point per step along the longer axis
+    of every edge, the points where the outline changes column give the crossings of the pixel columns, and the
+    column-major run lengths between sorted crossings alternate outside / inside."""
+    xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+    k = xy.shape[0]
+    scale = 5.0
+    x = np.floor(scale * xy[:, 0] + 0.5).astype(np.int64)
+    y = np.floor(scale * xy[:, 1] + 0.5).astype(np.int64)
+    x, y = np.append(x, x[0]), np.append(y, y[0])
+    us, vs = [], []
+    for j in range(k):
+        xs, xe, ys, ye = int(x[j]), int(x[j + 1]), int(y[j]), int(y[j + 1])
+        dx, dy = abs(xe - xs), abs(ys - ye)
+        flip = (dx >= dy and xs > xe) or (dx < dy and ys > ye)
+        if flip:
+            xs, xe, ys, ye = xe, xs, ye, ys
+        if dx >= dy:
+            sl = (ye - ys) / dx if dx else 0.0
+            d = np.arange(dx + 1)
+            t = dx - d if flip else d
+            us.append(t + xs)
+            vs.append(np.floor(ys + sl * t + 0.5).astype(np.int64))
+        else:
+            sl = (xe - xs) / dy
+            d = np.arange(dy + 1)
+            t = dy - d if flip else d
+            vs.append(t + ys)
+            us.append(np.floor(xs + sl * t + 0.5).astype(np.int64))
+    u, v = np.concatenate(us), np.concatenate(vs)
+    # crossings of the pixel columns, downsampled
+    ch = np.flatnonzero(u[1:] != u[:-1]) + 1
+    uj, up, vj, vp = u[ch], u[ch - 1], v[ch], v[ch - 1]
+    xd = (np.where(uj < up, uj, uj - 1).astype(np.float64) + 0.5) / scale - 0.5
+    ok = (np.floor(xd) == xd) & (xd >= 0) & (xd <= w - 1)
+    yd = (np.minimum(vj, vp).astype(np.float64) + 0.5) / scale - 0.5
+    yd = np.ceil(np.clip(yd, 0, h))
+    a = np.sort((xd[ok].astype(np.int64) * h + yd[ok].astype(np.int64)))
+    a = np.append(a, h * w)
+    runs = np.diff(np.concatenate([[0], a]))
+    # zero-length runs join their neighbours (two crossings at one place cancel)
+    b = []
+    j = 0
+    b.append(int(runs[j])); j += 1
+    while j < len(runs):
+        if runs[j] > 0:
+            b.append(int(runs[j])); j += 1
+        else:
+            j += 1
+            if j < len(runs):
+                b[-1] += int(runs[j]); j += 1
+    flat = np.zeros(h * w, dtype=bool)
+    pos, val = 0, False
+    for c in b:
+        if val:
+            flat[pos:pos + c] = True
+        pos += c
+        val = not val
+    return flat.reshape(w, h).T
+
+
+def segmentation_to_mask(segm, image_size) -> torch.Tensor:
+    """lvis.py:94-115: polygons (union), a COCO run-length dict (compressed string or counts list), or a mask array;
+    ``image_size`` is Pillow's (width, height)."""
+    from ..segment_anything.amg import coco_decode_rle, rle_to_mask
+    w, h = image_size
+    if isinstance(segm, list):
+        m = np.zeros((h, w), dtype=bool)
+        for poly in segm:
+            m |= polygon_to_mask(poly, h, w)
+        return torch.from_numpy(m.astype(np.uint8))
+    if isinstance(segm, dict):
+        counts = segm["counts"]
+        if isinstance(counts, bytes):
+            counts = counts.decode("ascii")
+        rle = coco_decode_rle({"size": segm["size"], "counts": counts}) if isinstance(counts, str) else segm
+        return torch.from_numpy(rle_to_mask(rle).astype(np.uint8))
+    arr = np.asarray(segm)
+    assert arr.ndim == 2, f"Expect segmentation of 2 dimensions, got {arr.ndim}."
+    return torch.from_numpy(arr.astype(np.uint8))
+
+
+class DatasetLVIS(torch.utils.data.Dataset):
+    """LVIS-92i (/root/reference/matcher/data/lvis.py:15-189): ``<datapath>/LVIS/lvis_{train,val}.pkl`` hold
+    {category id: {image name: {"annotations": [{"segmentation": ...}]}}} and the images live under
+    ``<datapath>/LVIS/coco``.  Validation categories are those with more than ``shot`` images, dealt to ten folds
+    (``val_cat_ids[fold + 10 v]``); 2300 test episodes walk the fold's classes in turn, query and supports drawn from
+    the class's images; a mask is the union of the image's annotations of the class.  The tables are read as plain
+    data (nothing from the pickles is executed)."""
+
+    def __init__(self, datapath: str, fold: int, transform: EpisodeTransform, split: str, shot: int, use_original_imgsize: bool = False):
+        from ..io import read_plain_pickle
+        self.split = "val" if split in ("val", "test") else "trn"
+        self.fold, self.nfolds, self.benchmark, self.shot, self.transform = fold, 10, "lvis", shot, transform
+        self.use_original_imgsize = use_original_imgsize
+        self.anno_path = os.path.join(datapath, "LVIS")
+        self.base_path = os.path.join(datapath, "LVIS", "coco")
+        train = read_plain_pickle(os.path.join(self.anno_path, "lvis_train.pkl"), max_bytes=1 << 34)
+        val = read_plain_pickle(os.path.join(self.anno_path, "lvis_val.pkl"), max_bytes=1 << 34)
+        train_ids = list(train.keys())
+        val_ids = [c for c in val.keys() if len(val[c]) > shot]
+        ids_val = [val_ids[fold + self.nfolds * v] for v in range(len(val_ids) // self.nfolds)]
+        ids_trn = [c for c in train_ids if c not in ids_val]
+        self.class_ids_ori = ids_trn if self.split == "trn" else ids_val
+        self.nclass = len(train_ids) if self.split == "trn" else len(val_ids)
+        self.img_metadata_classwise = train if self.split == "trn" else val
+        self.class_ids_c = {cid: i for i, cid in enumerate(self.class_ids_ori)}
+        self.class_ids = sorted(self.class_ids_c.values())
+        self.img_metadata = sorted({n for names in self.img_metadata_classwise.values() for n in names})
+
+    def __len__(self):
+        return len(self.img_metadata) if self.split == "trn" else 2300
+
+    def _mask(self, info: dict, size) -> torch.Tensor:
+        parts = [segmentation_to_mask(a["segmentation"], size)[None].float() for a in info["annotations"]]
+        return (torch.cat(parts, dim=0).sum(0) > 0).to(torch.uint8)
+
+    def __getitem__(self, idx: int) -> dict:
+        from PIL import Image
+        idx %= len(self.class_ids)
+        c = self.class_ids_ori[idx]
+        table = self.img_metadata_classwise[c]
+        names = list(table.keys())
+        query = np.random.choice(names, 1, replace=False)[0]
+        q_img = Image.open(os.path.join(self.base_path, query)).convert("RGB")
+        q_mask = self._mask(table[query], q_img.size)
+        support = []
+        while len(support) < self.shot:
+            s = np.random.choice(names, 1, replace=False)[0]
+            if s != query:
+                support.append(s)
+        s_imgs = [Image.open(os.path.join(self.base_path, s)).convert("RGB") for s in support]
+        s_masks = [self._mask(table[s], im.size) for s, im in zip(support, s_imgs)]
+        b = _batch(self.transform, q_img, q_mask, s_imgs, s_masks, str(query), [str(s) for s in support], self.class_ids_c[c])
+        b["org_query_imsize"] = q_img.size
+        return b
 
 
 class DatasetSynthetic(torch.utils.data.Dataset):

@@ -99,7 +99,7 @@ def test_fss_reader(mods, tmp_path):
     im = Image.open(b["query_name"][0]).convert("RGB").resize((28, 28), Image.BILINEAR)
     assert torch.equal(b["query_img"][0], torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float() / 255)
     with pytest.raises(NotImplementedError):
-        data.FSSDataset.build_dataloader("lvis", 1, 0, 0, "test")
+        data.FSSDataset.build_dataloader("pascal_part", 1, 0, 0, "test")
 
 
 def test_coco_reader(mods, tmp_path):
@@ -189,6 +189,82 @@ def test_pascal5i_reader(mods, tmp_path):
     logger = importlib.import_module(mods[0].__name__.rsplit(".", 1)[0] + ".mars.utils.logger")
     meter = logger.AverageMeter(ds, device="cpu")
     assert meter.class_ids_interest.tolist() == [5, 6, 7, 8, 9] and meter.nclass == 20
+
+
+def test_polygon_rasteriser(mods):
+    """The COCO polygon rule restated: an integer rectangle covers exactly its w x h pixels, areas follow the shoelace
+    formula to within the outline, and the result differs from Pillow's polygon fill only along the outline."""
+    from PIL import Image, ImageDraw
+    ep = importlib.import_module(mods[1].__name__ + ".episodes")
+    m = ep.polygon_to_mask([2, 3, 7, 3, 7, 9, 2, 9], 12, 10)
+    want = np.zeros((12, 10), bool)
+    want[3:9, 2:7] = True
+    assert np.array_equal(m, want)
+    assert np.array_equal(ep.polygon_to_mask([7, 9, 2, 9, 2, 3, 7, 3], 12, 10), want)            # orientation and start do not matter
+    assert ep.polygon_to_mask([-5, -5, 30, -5, 30, 30, -5, 30], 12, 10).all()                   # clipped to the image
+    g = np.random.default_rng(0)
+    for _ in range(8):
+        pts = (g.random((7, 2)) * [60, 40]).round(2)
+        c = pts.mean(0)
+        pts = pts[np.argsort(np.arctan2(pts[:, 1] - c[1], pts[:, 0] - c[0]))]
+        m = ep.polygon_to_mask(pts.reshape(-1), 40, 60)
+        x, y = pts[:, 0], pts[:, 1]
+        area = 0.5 * abs(np.dot(x, np.roll(y, 1)) - np.dot(y, np.roll(x, 1)))
+        per = np.hypot(x - np.roll(x, 1), y - np.roll(y, 1)).sum()
+        im = Image.new("L", (60, 40), 0)
+        ImageDraw.Draw(im).polygon([tuple(p) for p in pts], fill=1)
+        assert abs(m.sum() - area) <= 0.5 * per and int((m ^ np.asarray(im).astype(bool)).sum()) <= per
+
+
+def test_lvis_reader(mods, tmp_path):
+    """LVIS-92i: validation categories with more than `shot` images dealt to ten folds, episodes walking the fold's
+    classes, masks as unions of polygon / run-length / array annotations."""
+    _, data = mods
+    amg = importlib.import_module(mods[1].__name__.rsplit(".", 1)[0] + ".segment_anything.amg")
+    rng = np.random.default_rng(7)
+    base = tmp_path / "LVIS"
+    names = [f"val2017/{i:03d}.jpg" for i in range(6)]
+    _write_images(str(base / "coco"), names, rng)                       # 40 x 30 images
+    rect = lambda x0, y0, x1, y1: [float(v) for v in (x0, y0, x1, y0, x1, y1, x0, y1)]   # noqa: E731
+    arr = np.zeros((30, 40), np.uint8)
+    arr[20:25, 30:38] = 1
+    rle_mask = np.zeros((30, 40), bool)
+    rle_mask[1:4, 1:9] = True
+    rle = amg.coco_encode_rle(amg.mask_to_rle(rle_mask))
+    ann = lambda segs: {"annotations": [{"segmentation": s} for s in segs]}   # noqa: E731
+    val = {}
+    for k in range(25):                                                 # 25 categories; category 3 has a single image
+        cat = 100 + k
+        imgs = names[:1] if k == 3 else names[k % 3: k % 3 + 3]
+        val[cat] = {n: ann([[rect(5, 6, 15, 16)], rle]) for n in imgs}
+    val[100][names[0]] = ann([[rect(5, 6, 15, 16), rect(20, 2, 30, 8)], {"size": [30, 40], "counts": amg.mask_to_rle(rle_mask)["counts"]}])
+    train = {100: val[100], 101: val[101], 999: val[102]}
+    os.makedirs(base, exist_ok=True)
+    (base / "lvis_val.pkl").write_bytes(pickle.dumps(val))
+    (base / "lvis_train.pkl").write_bytes(pickle.dumps(train))
+    data.FSSDataset.initialize(img_size=28, datapath=str(tmp_path), use_original_imgsize=False)
+    np.random.seed(1)
+    ds = data.FSSDataset.build_dataloader("lvis", 1, 0, 0, "test", shot=1).dataset
+    kept = [c for c in val if c != 103]                                 # more than one image
+    assert len(ds) == 2300 and ds.nclass == 24 and ds.class_ids_ori == [kept[0], kept[10]] and ds.class_ids == [0, 1]
+    assert ds.img_metadata == sorted(names[:5])
+    found = False
+    for i in range(6):
+        b = ds[2 * i]                                                   # class index 0 = category 100
+        assert int(b["class_id"]) == 0 and b["support_names"][0] != b["query_name"] and b["query_img"].shape == (3, 28, 28)
+        if b["query_name"] == names[0]:
+            full = np.zeros((30, 40), np.float32)
+            full[6:16, 5:15] = 1
+            full[2:8, 20:30] = 1
+            full[1:4, 1:9] = 1
+            want = torch.nn.functional.interpolate(torch.from_numpy(full)[None, None], (28, 28), mode="nearest")[0, 0]
+            assert torch.equal(b["query_mask"], want) and b["org_query_imsize"] == (40, 30)
+            found = True
+    assert found
+    ep = importlib.import_module(mods[1].__name__ + ".episodes")
+    assert torch.equal(ep.segmentation_to_mask(arr, (40, 30)), torch.from_numpy(arr))
+    trn = data.DatasetLVIS(str(tmp_path), 0, data.EpisodeTransform(28), "trn", 1)
+    assert trn.class_ids_ori == [101, 999] and trn.nclass == 3          # category 100 is a validation class of fold 0
 
 
 def test_synthetic_dataset(mods):
