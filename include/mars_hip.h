@@ -104,7 +104,7 @@ int marship_flash_attn(const void* qkv, void* O, float* lse, int B, int T, int H
                        void* stream);
 /* The same attention with q, k, v and the probabilities quantised to 8-bit floats (OCP e4m3, one scale per image,
  * head and operand) and both contractions on the fp8 MFMA; f32 softmax and accumulation, no mask, no lse.  The caller
- * brings the workspace: q8, k8 [B*H*Tp*64] bytes, vt8 [B*H*64*Tp] bytes, scales [B*H*3] f32, Tp = T rounded up to 32.
+ * brings the workspace: q8, k8 [B*H*Tp*64] bytes, vt8 [B*H*64*Tp] bytes, scales [B*H*6] f32 (factors, then maxima), Tp = T rounded up to 32.
  * For the configuration that names an fp8 attention path; the reference (attention.py:54-60; alpha_clip/model.py:233-246)
  * has no such mode. */
 int marship_flash_attn_fp8(const void* qkv, void* O, int B, int T, int H, void* q8, void* k8, void* vt8, float* scales,

@@ -4,8 +4,8 @@
 // quantisation; the configuration that asks for it trades precision, not speed: with 64-wide heads the kernel is
 // bound by the exponentials, as the bf16 one is.
 //
-// Two launches: `quant_qkv_fp8_kernel` scales every (image, head) slice of q, k and v by 448 / amax of the slice and
-// writes q8 / k8 [B*H, Tp, 64] and v transposed, vt8 [B*H, 64, Tp] (rows beyond T are zero, Tp a multiple of 32);
+// Three launches: `amax_qkv_kernel` finds the largest magnitude of every (image, head) slice of q, k and v;
+// `quant_qkv_fp8_kernel` scales the slices by 448 / amax and writes q8 / k8 [B*H, Tp, 64] and v transposed, vt8 [B*H, 64, Tp] (rows beyond T are zero, Tp a multiple of 32);
 // `flash_attn_fp8_kernel` gives every wave 64 queries and walks the keys 32 at a time.  The scores are formed
 // transposed (S^T = K Q^T: keys are MFMA rows, a query is a lane column), so a lane holds, for its query, keys
 // 4g..4g+3 of both 16-key halves of the tile - exactly the eight contraction slots the second product
@@ -55,52 +55,69 @@ __device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d
     return (uint32_t)w;
 }
 
-__global__ __launch_bounds__(512) void quant_qkv_fp8_kernel(const __bf16* __restrict__ qkv, int T, int Tp, int H,
-                                                            uint8_t* __restrict__ q8, uint8_t* __restrict__ k8,
-                                                            uint8_t* __restrict__ vt8, float* __restrict__ scales) {
-    __shared__ float sm[16];
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+// eight floats -> eight fp8 bytes
+__device__ __forceinline__ uint2 pack8_fp8(const bf16x8& v, float inv) {
+    return make_uint2(pack4_fp8((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv),
+                      pack4_fp8((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv));
+}
+
+// Pass 1: largest magnitude of every (image, operand, head) slice.  A workgroup takes 32 token rows of one image and
+// reads them whole (a thread keeps its 16-byte columns and walks down the rows, so every load instruction covers
+// contiguous memory); the eight threads that share a head join their maxima and one of them adds the result with an
+// integer atomic maximum on the bit pattern (non-negative floats order like integers: exact, order independent).
+// amax: [B][3][H] as bit patterns, zeroed by the caller.
+__global__ __launch_bounds__(256) void amax_qkv_kernel(const __bf16* __restrict__ qkv, int T, int H, unsigned* __restrict__ amax) {
+    const int b = blockIdx.y, r0 = blockIdx.x * 32, r1 = min(r0 + 32, T);
+    const int nch = 3 * H * 8;                                           // 16-byte chunks per row
+    const int64_t ld = 3LL * H * 64;
+    const __bf16* base = qkv + (int64_t)b * T * ld;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        float m = 0.f;
+#pragma unroll 4
+        for (int r = r0; r < r1; ++r) {
+            const bf16x8 v = *(const bf16x8*)(base + (int64_t)r * ld + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)v[j]));
+        }
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = fmaxf(m, __shfl_xor(m, 4, 64));
+        if ((c & 7) == 0) atomicMax(amax + (int64_t)b * 3 * H + (c >> 3), __builtin_bit_cast(unsigned, m));
+    }
+}
+
+// Pass 2: one workgroup per (image, head) and 32 tokens: q8, k8 rows (a thread packs eight dims of one token) and the
+// transposed vt8 (a thread packs eight tokens of one dim).  Rows beyond T are zero.
+__global__ __launch_bounds__(256) void quant_qkv_fp8_kernel(const __bf16* __restrict__ qkv, int T, int Tp, int H,
+                                                            const unsigned* __restrict__ amax, uint8_t* __restrict__ q8,
+                                                            uint8_t* __restrict__ k8, uint8_t* __restrict__ vt8,
+                                                            float* __restrict__ scales) {
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, k0 = blockIdx.x * 32;
     const int64_t ld = 3LL * H * 64;
     const __bf16* base = qkv + (int64_t)b * T * ld + h * 64;
-    float inv[3], mx[3] = {0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int e = threadIdx.x; e < T * 16; e += blockDim.x) {
-        const int t = e >> 4, d4 = (e & 15) * 4;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const bf16x4 v = *(const bf16x4*)(base + (int64_t)t * ld + s * H * 64 + d4);
-            mx[s] = fmaxf(mx[s], fmaxf(fmaxf(fabsf((float)v[0]), fabsf((float)v[1])), fmaxf(fabsf((float)v[2]), fabsf((float)v[3]))));
-        }
-    }
+    float inv[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const float m = fmaxf(block_reduce_max(mx[s], sm), 1e-20f);
+        const float m = fmaxf(__builtin_bit_cast(float, amax[(int64_t)b * 3 * H + s * H + h]), 1e-20f);
         inv[s] = FP8_MAX / m;
-        if (threadIdx.x == 0) scales[bh * 3 + s] = m / FP8_MAX;          // dequantisation factor
+        if (blockIdx.x == 0 && threadIdx.x == 0) scales[bh * 3 + s] = m / FP8_MAX;          // dequantisation factor
     }
-    // q8, k8: [Tp, 64] rows, four dims per thread; rows beyond T are zero
-#pragma unroll 4
-    for (int e = threadIdx.x; e < Tp * 16; e += blockDim.x) {
-        const int t = e >> 4, d4 = (e & 15) * 4;
-        uint32_t wq = 0, wk = 0;
+    {
+        const int t = k0 + (threadIdx.x >> 3), d8 = (threadIdx.x & 7) * 8;
+        uint2 wq = make_uint2(0, 0), wk = make_uint2(0, 0);
         if (t < T) {
-            const bf16x4 q = *(const bf16x4*)(base + (int64_t)t * ld + d4);
-            const bf16x4 k = *(const bf16x4*)(base + (int64_t)t * ld + H * 64 + d4);
-            wq = pack4_fp8((float)q[0] * inv[0], (float)q[1] * inv[0], (float)q[2] * inv[0], (float)q[3] * inv[0]);
-            wk = pack4_fp8((float)k[0] * inv[1], (float)k[1] * inv[1], (float)k[2] * inv[1], (float)k[3] * inv[1]);
+            wq = pack8_fp8(*(const bf16x8*)(base + (int64_t)t * ld + d8), inv[0]);
+            wk = pack8_fp8(*(const bf16x8*)(base + (int64_t)t * ld + H * 64 + d8), inv[1]);
         }
-        *(uint32_t*)(q8 + ((int64_t)bh * Tp + t) * 64 + d4) = wq;
-        *(uint32_t*)(k8 + ((int64_t)bh * Tp + t) * 64 + d4) = wk;
+        *(uint2*)(q8 + ((int64_t)bh * Tp + t) * 64 + d8) = wq;
+        *(uint2*)(k8 + ((int64_t)bh * Tp + t) * 64 + d8) = wk;
     }
-    // vt8: [64, Tp], four keys per thread (the dim runs fastest over the threads so the reads of a row coalesce)
-#pragma unroll 2
-    for (int e = threadIdx.x; e < (Tp / 4) * 64; e += blockDim.x) {
-        const int d = e & 63, t4 = (e >> 6) * 4;
-        float v[4];
+    {
+        const int d = threadIdx.x & 63, t8 = k0 + (threadIdx.x >> 6) * 8;
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            v[j] = t4 + j < T ? (float)base[(int64_t)(t4 + j) * ld + 2 * H * 64 + d] * inv[2] : 0.f;
-        *(uint32_t*)(vt8 + ((int64_t)bh * 64 + d) * Tp + t4) = pack4_fp8(v[0], v[1], v[2], v[3]);
+        for (int j = 0; j < 8; ++j) v[j] = t8 + j < T ? (float)base[(int64_t)(t8 + j) * ld + 2 * H * 64 + d] * inv[2] : 0.f;
+        *(uint2*)(vt8 + ((int64_t)bh * 64 + d) * Tp + t8) = make_uint2(pack4_fp8(v[0], v[1], v[2], v[3]), pack4_fp8(v[4], v[5], v[6], v[7]));
     }
 }
 
@@ -235,11 +252,15 @@ extern "C" int marship_flash_attn_fp8(const void* qkv, void* O, int B, int T, in
                                       float* scales, int Tp, void* stream) {
     MARS_CHECK(qkv && O && q8 && k8 && vt8 && scales, "flash_attn_fp8: null pointer");
     MARS_CHECK(B > 0 && T > 0 && H > 0 && Tp >= T && Tp % 32 == 0 && Tp - T < 32, "flash_attn_fp8: bad shape B=%d T=%d H=%d Tp=%d", B, T, H, Tp);
-    MARS_CHECK(((uintptr_t)qkv % 8) == 0 && ((uintptr_t)O % 8) == 0 && ((uintptr_t)q8 % 8) == 0 && ((uintptr_t)k8 % 8) == 0 &&
+    MARS_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)O % 8) == 0 && ((uintptr_t)q8 % 8) == 0 && ((uintptr_t)k8 % 8) == 0 &&
                ((uintptr_t)vt8 % 4) == 0, "flash_attn_fp8: operands must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(quant_qkv_fp8_kernel, dim3(B * H), dim3(512), 0, s, (const __bf16*)qkv, T, Tp, H, (uint8_t*)q8, (uint8_t*)k8,
-                       (uint8_t*)vt8, scales);
+    unsigned* amax = (unsigned*)(scales + (int64_t)B * H * 3);          // second half of the scales workspace
+    MARS_CHECK(hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)B * H * 3, s) == hipSuccess, "flash_attn_fp8: memset failed");
+    hipLaunchKernelGGL(amax_qkv_kernel, dim3((T + 31) / 32, B), dim3(256), 0, s, (const __bf16*)qkv, T, H, amax);
+    MARS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(quant_qkv_fp8_kernel, dim3(Tp / 32, B * H), dim3(256), 0, s, (const __bf16*)qkv, T, Tp, H, amax, (uint8_t*)q8,
+                       (uint8_t*)k8, (uint8_t*)vt8, scales);
     MARS_LAUNCH_CHECK();
     hipLaunchKernelGGL(flash_attn_fp8_kernel, dim3((T + 64 * QB - 1) / (64 * QB), B * H), dim3(256), 0, s, (const uint8_t*)q8, (const uint8_t*)k8,
                        (const uint8_t*)vt8, scales, T, Tp, H, (__bf16*)O);

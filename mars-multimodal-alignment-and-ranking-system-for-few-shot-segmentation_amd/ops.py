@@ -228,7 +228,7 @@ def flash_attn_fp8(qkv: torch.Tensor, O: torch.Tensor, B: int, T: int, H: int, w
     if ws.get("key") != key:
         n = B * H * Tp * 64
         ws.update(key=key, q8=torch.zeros(n, dtype=torch.uint8, device=qkv.device), k8=torch.zeros(n, dtype=torch.uint8, device=qkv.device),
-                  vt8=torch.zeros(n, dtype=torch.uint8, device=qkv.device), scales=torch.zeros(B * H * 3, dtype=torch.float32, device=qkv.device))
+                  vt8=torch.zeros(n, dtype=torch.uint8, device=qkv.device), scales=torch.zeros(B * H * 6, dtype=torch.float32, device=qkv.device))
     hip.check(hip.lib().marship_flash_attn_fp8(ptr(qkv), ptr(O), B, T, H, ptr(ws["q8"]), ptr(ws["k8"]), ptr(ws["vt8"]), ptr(ws["scales"]),
                                                Tp, stream()), "marship_flash_attn_fp8")
 
