@@ -173,8 +173,10 @@ int marship_proposal_stats(const uint8_t* bits, int N, int P, const float* vva, 
 /* AlphaCLIP score: s[n] = <f_n/|f_n|, t/|t|> (FilteringMergingModule.py:97,179,200). */
 int marship_cosine_scores(const float* feats, int64_t ldf, int N, int E, const float* text,
                           float* scores, void* stream);
-/* Scores, ranking and keep decision in float64 (FilteringMergingModule.py:118-138,213-217):
- * order[k] = index of the k-th best proposal (stable), keep[n] in {0,1}. */
+/* Scores, ranking and keep decision (FilteringMergingModule.py:118-138,213-217) in the number types of
+ * the reference's numpy expressions: EMD min-max and the mean of four in float64, the AlphaCLIP min-max
+ * in float32.  order[k] = index of the k-th best proposal (stable), keep[n] in {0,1}.  A proposal whose
+ * score is not finite (emd NaN: no patches) ranks after every finite one and is not kept. */
 int marship_rank(const double* emd, const float* aclip, const int32_t* cnt, const float* sum_vva,
                  const float* sum_vta, const int32_t* union_cnt, int N, double alpha,
                  double static_thr, double dynamic_thr, double* score, int32_t* order,

@@ -76,6 +76,8 @@ def test_MARS(args) -> dict:
     random.seed(0)
     utils.fix_randseed(0)
     args.dtype = torch.bfloat16 if args.dtype in ("bf16", torch.bfloat16) else torch.float32
+    if torch.device(args.device).type == "cuda":
+        torch.cuda.set_device(args.device)       # kernels launch on the current device: make it the one asked for
 
     state_dicts = None
     if args.synthetic:

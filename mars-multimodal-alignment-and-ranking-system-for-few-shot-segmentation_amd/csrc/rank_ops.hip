@@ -385,22 +385,30 @@ __global__ __launch_bounds__(256) void cosine_scores_kernel(const float* __restr
     if (lane == 0) scores[n] = d;
 }
 
-// ------------------------------------------------------------ ranking (float64, single block)
+// ------------------------------------------------------------ ranking (single block)
+// Number types follow the numpy expressions of FilteringMergingModule._score_proposals (:108-136): the pooled
+// sums are float32 sums divided in float64, the EMD min-max runs in float64 (ot.emd2 returns float64), the
+// AlphaCLIP min-max stays in float32 (float32 cosines with a Python-float epsilon), the mean of four is float64.
+// A non-finite score (the host solver returns NaN for a proposal without patches) ranks last and is never kept.
+__device__ __forceinline__ double rank_key(double s) { return isfinite(s) ? s : -INFINITY; }
+
 __global__ __launch_bounds__(1024) void rank_kernel(const double* __restrict__ emd, const float* __restrict__ aclip,
                                                     const int32_t* __restrict__ cnt, const float* __restrict__ svv,
                                                     const float* __restrict__ svt, const int32_t* __restrict__ ucnt, int N,
                                                     double alpha, double sthr, double dthr, double* __restrict__ score,
                                                     int32_t* __restrict__ order, uint8_t* __restrict__ keep) {
     __shared__ double sc[1024];
-    __shared__ double red[4];  // emd min/max, aclip min/max
+    __shared__ double red[2];  // emd min/max, then the keep threshold
+    __shared__ float redf[2];  // aclip min/max
     const int i = threadIdx.x;
     if (i == 0) {
-        double emn = INFINITY, emx = -INFINITY, amn = INFINITY, amx = -INFINITY;
+        double emn = INFINITY, emx = -INFINITY;
+        float amn = INFINITY, amx = -INFINITY;
         for (int k = 0; k < N; ++k) {
             emn = fmin(emn, emd[k]); emx = fmax(emx, emd[k]);
-            amn = fmin(amn, (double)aclip[k]); amx = fmax(amx, (double)aclip[k]);
+            amn = fminf(amn, aclip[k]); amx = fmaxf(amx, aclip[k]);
         }
-        red[0] = emn; red[1] = emx; red[2] = amn; red[3] = amx;
+        red[0] = emn; red[1] = emx; redf[0] = amn; redf[1] = amx;
     }
     __syncthreads();
     if (i < N) {
@@ -409,25 +417,28 @@ __global__ __launch_bounds__(1024) void rank_kernel(const double* __restrict__ e
         const double pvv = alpha * ((double)svv[i] / (1e-7 + c)) + (1.0 - alpha) * cov;
         const double pvt = alpha * ((double)svt[i] / (1e-7 + c)) + (1.0 - alpha) * cov;
         const double es = (emd[i] - red[0]) / (1e-7 + red[1] - red[0]);
-        const double as = ((double)aclip[i] - red[2]) / (1e-7 + red[3] - red[2]);
-        sc[i] = (es + as + pvv + pvt) / 4.0;
+        const float as = __fdiv_rn(__fsub_rn(aclip[i], redf[0]), __fsub_rn(__fadd_rn(1e-7f, redf[1]), redf[0]));
+        sc[i] = (es + (double)as + pvv + pvt) / 4.0;
         score[i] = sc[i];
     }
     __syncthreads();
     if (i < N) {
         int rank = 0;
-        const double s = sc[i];
-        for (int k = 0; k < N; ++k) rank += (sc[k] > s || (sc[k] == s && k < i)) ? 1 : 0;
+        const double s = rank_key(sc[i]);
+        for (int k = 0; k < N; ++k) {
+            const double t = rank_key(sc[k]);
+            rank += (t > s || (t == s && k < i)) ? 1 : 0;
+        }
         order[rank] = i;
     }
     __syncthreads();
     if (i == 0) {
         double top = -INFINITY;
-        for (int k = 0; k < N; ++k) top = fmax(top, sc[k]);
+        for (int k = 0; k < N; ++k) top = fmax(top, rank_key(sc[k]));
         red[0] = top < sthr ? dthr * top : sthr;
     }
     __syncthreads();
-    if (i < N) keep[i] = sc[i] >= red[0] ? 1 : 0;
+    if (i < N) keep[i] = (isfinite(sc[i]) && sc[i] >= red[0]) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void merge_masks_kernel(const float* __restrict__ masks, const uint8_t* __restrict__ keep,

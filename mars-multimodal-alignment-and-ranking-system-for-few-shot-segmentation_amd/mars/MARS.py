@@ -50,6 +50,14 @@ class MARS:
 
     def predict(self, support_images: torch.Tensor, support_masks: torch.Tensor, query_image: torch.Tensor,
                 mask_proposals: Optional[torch.Tensor] = None):
+        # the kernels run on the current device's current stream: make the components' GPU current for the call
+        device = getattr(self.filtering_merging_component, "device", None)
+        if isinstance(device, torch.device) and device.type == "cuda":
+            with torch.cuda.device(device):
+                return self._predict(support_images, support_masks, query_image, mask_proposals)
+        return self._predict(support_images, support_masks, query_image, mask_proposals)
+
+    def _predict(self, support_images, support_masks, query_image, mask_proposals):
         self.time_start_ranking = time.time()
         assert (mask_proposals is not None or self.mask_generator is not None)
         if self.mask_generator is not None:
@@ -83,7 +91,7 @@ class MARS:
         ops.resample_axis(vta.contiguous(), 1, Gv, Gv, 1, t, tmp)
         ops.resample_axis(tmp, 1, Gv, G, 0, t, vta_g)
         ops.minmax(vta_g.view(-1), vta_g.view(-1))
-        self.vva, self.vta = vva, vta_g
+        self.vva, self.vta = vva.clone(), vta_g
 
         handle = vva_mod.similarity_handle() if hasattr(vva_mod, "similarity_handle") else None
         predicted_mask = self.filtering_merging_component.compute(
@@ -91,7 +99,10 @@ class MARS:
             cost_matrix=handle if handle is not None else vva_mod.cost_matrix,
             patch_features_spatial_dimension=vva_mod.model_embedding_spatial_dimensions,
             vva=vva, vta=vta_g, text=text_alpha_clip)
-        torch.cuda.synchronize()  # kernels are asynchronous: the end stamp must include them
+        # the components write into buffers they reuse on the next call; the reference hands out fresh
+        # tensors (FilteringMergingModule.py:219), so the caller gets a copy that the next predict() leaves alone
+        predicted_mask = predicted_mask.clone()
+        torch.cuda.synchronize(dev)  # kernels are asynchronous: the end stamp must include them
         self.time_end_ranking = time.time()
         return predicted_mask
 

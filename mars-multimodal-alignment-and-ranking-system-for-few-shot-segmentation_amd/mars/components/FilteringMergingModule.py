@@ -21,6 +21,18 @@ from .VisualVisualAlignmentModule import SimilarityHandle
 from .VisualTextAlignmentModule import CLIP_MEAN, CLIP_STD
 
 
+def default_emd_threads() -> int:
+    """Host threads for the transport solver of one process: the cores this process may run on (at most
+    16: a query has 64 problems and the solver stops scaling there), shared evenly between the ranks that
+    a launcher placed on this node (LOCAL_WORLD_SIZE, else WORLD_SIZE)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    return max(1, min(16, cores // max(ranks, 1)))
+
+
 class FilteringMergingModule:
     def __init__(self, alpha_clip_model, img_transforms, mask_transforms, alpha: float, static_threshold: float,
                  dynamic_threshold: float, device, tokenizer: Optional[Callable] = None, emd_threads: int = 0):
@@ -36,7 +48,7 @@ class FilteringMergingModule:
             from ...tokenizer import default_tokenizer
             tokenizer = default_tokenizer()   # merge-table BPE when MARS_BPE_PATH is set, else the bundled prompt ids
         self.tokenizer = tokenizer
-        self.emd_threads = emd_threads or int(os.environ.get("MARS_EMD_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        self.emd_threads = emd_threads or int(os.environ.get("MARS_EMD_THREADS", "0")) or default_emd_threads()
         self._mean = torch.tensor(CLIP_MEAN, dtype=torch.float32, device=self.device)
         self._std = torch.tensor(CLIP_STD, dtype=torch.float32, device=self.device)
         self._tables: Dict = {}
@@ -177,12 +189,7 @@ class FilteringMergingModule:
             joined = None
         # lines 112-116, 142-169: ... while the host solves the N transport problems
         ev.synchronize()
-        if isinstance(cost_matrix, SimilarityHandle):
-            emd = ops.emd_scores_host(cost_matrix.wait(), w["fg_host"], w["bits_host"], self.emd_threads, is_cost=False)
-        else:
-            cm = cost_matrix.detach().cpu().float().contiguous()
-            emd = ops.emd_scores_host(cm, w["fg_host"], w["bits_host"], self.emd_threads, is_cost=True)
-        w["emd"].copy_(emd, non_blocking=False)
+        w["emd"].copy_(self._compute_emd_scores(cost_matrix, w["fg_host"], w["bits_host"]), non_blocking=False)
         if joined is not None:
             torch.cuda.current_stream(dev).wait_event(joined)
         ops.cosine_scores(feats, tfeat, w["aclip"])
@@ -191,6 +198,15 @@ class FilteringMergingModule:
                  self.dynamic_threshold, w["score"], w["order"], w["keep"])
         self.last = dict(w=w, masks=masks, N=N)
         return w
+
+    def _compute_emd_scores(self, cost_matrix, fg_host: torch.Tensor, bits_host: torch.Tensor) -> torch.Tensor:
+        """Lines 112-116 / 142-169 for all proposals at once: float64 [N] of 1 - emd2 between the uniform
+        distributions on the support's foreground patches (``fg_host`` u8 [ns*P]) and on each proposal's
+        patches (``bits_host`` u8 [N, P]), solved exactly on host threads."""
+        if isinstance(cost_matrix, SimilarityHandle):
+            return ops.emd_scores_host(cost_matrix.wait(), fg_host, bits_host, self.emd_threads, is_cost=False)
+        cm = cost_matrix.detach().cpu().float().contiguous()
+        return ops.emd_scores_host(cm, fg_host, bits_host, self.emd_threads, is_cost=True)
 
     def _merge_masks(self, ranked_masks=None) -> torch.Tensor:
         """Lines 209-221 on the keep flags the ranking kernel produced."""

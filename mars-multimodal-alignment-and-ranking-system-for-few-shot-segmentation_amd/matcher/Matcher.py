@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..mars.components.FilteringMergingModule import default_emd_threads
 from ..mars.components.VisualVisualAlignmentModule import IMAGENET_MEAN, IMAGENET_STD, _pad64
 
 
@@ -33,7 +34,7 @@ class RobustPromptSampler:
         self.encoder_feat_size = int(encoder_feat_size)
         self.sample_range = sample_range
         self.max_iterations = max_iterations
-        self.emd_threads = emd_threads or int(os.environ.get("MARS_EMD_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        self.emd_threads = emd_threads or int(os.environ.get("MARS_EMD_THREADS", "0")) or default_emd_threads()
 
     def get_mask_scores(self, points, masks: torch.Tensor, all_points, emd_cost: torch.Tensor, ref_masks_pool: torch.Tensor):
         """masks [n, 1, H, W] or [n, H, W] (bool / 0-1, on the GPU), all_points [K, 2] (x, y),

@@ -23,6 +23,7 @@ GEMM_PROFILE_DTYPE = BF16
 
 
 def stream() -> _vp:
+    """The current stream of the current device: ``_dev`` has checked that the operands live there."""
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
@@ -46,9 +47,19 @@ def _req(cond: bool, msg: str):
 
 
 def _dev(*ts):
+    """Every operand must live on the GPU that is current: the kernels are launched on the current
+    device's current stream, so an operand of another GPU would be reached across devices with no
+    ordering against that GPU's work.  Callers select the device first (``torch.cuda.set_device`` or a
+    ``torch.cuda.device`` block; ``MARS.predict`` and the builders do)."""
+    cur = None
     for t in ts:
         if t is not None:
             _req(t.is_cuda, "tensor must live on the GPU")
+            if cur is None:
+                cur = torch.cuda.current_device()
+            if t.device.index != cur:
+                raise ValueError(f"operand on cuda:{t.device.index} but the current device is cuda:{cur}: select the "
+                                 f"operands' device first (torch.cuda.set_device / torch.cuda.device)")
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,

@@ -220,11 +220,7 @@ def fmm_scores(aclip_sd, aclip_kw: dict, query_img, mask_proposals, support_mask
                text_tokens, *, alpha: float = 0.85, batch: int = 8):
     """/root/reference/mars/components/FilteringMergingModule.py:59-140.  Returns a dict
     with the four per-proposal score vectors, the combined score and the ranking."""
-    vta_np = vta.detach().cpu().numpy()
-    vva_np = vva.detach().cpu().numpy()
     pooled_support = pool_mask(support_mask.permute(1, 0, 2, 3), g)
-    union = (mask_proposals.sum(dim=0) > 0).float()
-    pooled_union = pool_mask(union[None], g)[0].numpy() > 0
 
     text = vit.clip_encode_text(aclip_sd, text_tokens, layers=aclip_kw["text_layers"], heads=aclip_kw["text_heads"])
     text = text / text.norm(dim=-1, keepdim=True)
@@ -237,27 +233,49 @@ def fmm_scores(aclip_sd, aclip_kw: dict, query_img, mask_proposals, support_mask
                                  heads=aclip_kw["heads"], patch=aclip_kw["patch"])
         feats.append(f / f.norm(dim=-1, keepdim=True))
     feats = torch.cat(feats, dim=0)
-    aclip = [float(s) for s in (feats @ text.t())[:, 0].numpy()]
+    aclip = (feats @ text.t())[:, 0].numpy()
 
-    emd, pvv, pvt = [], [], []
     sup = pooled_support.flatten().bool()
+    emd = []
+    for m in mask_proposals:
+        pm = pool_mask(m[None], g)[0].numpy() > 0
+        M = cost[sup, :][:, torch.from_numpy(pm).flatten()]
+        emd.append(1 - emd2_uniform(M.numpy().astype(np.float64)))
+    out = combine_scores(mask_proposals, g, vva, vta, np.asarray(emd), aclip, alpha=alpha)
+    out.update(feats=feats, text=text)
+    return out
+
+
+def combine_scores(mask_proposals, g: int, vva, vta, emd, aclip, *, alpha: float = 0.85):
+    """Lines 70-81 and 103-138 of FilteringMergingModule._score_proposals given the two model-dependent
+    lists: ``emd`` = 1 - emd2 per proposal (float64, what ``_compute_emd`` returns) and ``aclip`` = the
+    float32 cosines of line 97.  Dtypes follow the reference's numpy expressions: the pooled sums are
+    float32 sums divided in float64, the EMD min-max is float64, the AlphaCLIP min-max stays float32
+    (float32 array entries with a Python-float epsilon), the mean of the four is float64."""
+    vta_np = vta.detach().cpu().numpy()
+    vva_np = vva.detach().cpu().numpy()
+    union = (mask_proposals.sum(dim=0) > 0).float()
+    pooled_union = pool_mask(union[None], g)[0].numpy() > 0
+    emd = [np.float64(e) for e in emd]
+    aclip = [np.float32(a) for a in aclip]
+    pvv, pvt = [], []
     for m in mask_proposals:
         pm = pool_mask(m[None], g)[0].numpy() > 0
         cnt = np.sum(pm)
         cov = cnt / (1e-7 + np.sum(pooled_union))
         a_vv = np.sum(vva_np[pm]) / (1e-7 + cnt)
         a_vt = np.sum(vta_np[pm]) / (1e-7 + cnt)
-        M = cost[sup, :][:, torch.from_numpy(pm).flatten()]
-        emd.append(1 - emd2_uniform(M.numpy().astype(np.float64)))
         pvv.append(alpha * a_vv + (1 - alpha) * cov)
         pvt.append(alpha * a_vt + (1 - alpha) * cov)
     emd_s = [(s - min(emd)) / (1e-7 + max(emd) - min(emd)) for s in emd]
-    acl_s = [(s - min(aclip)) / (1e-7 + max(aclip) - min(aclip)) for s in aclip]
-    score = [(emd_s[i] + acl_s[i] + pvv[i] + pvt[i]) / 4 for i in range(len(emd))]
+    eps32 = np.float32(1e-7)
+    acl_s = [(s - min(aclip)) / (eps32 + max(aclip) - min(aclip)) for s in aclip]
+    assert all(a.dtype == np.float32 for a in acl_s)
+    score = [(emd_s[i] + np.float64(acl_s[i]) + pvv[i] + pvt[i]) / 4 for i in range(len(emd))]
     order = sorted(range(len(score)), key=lambda i: score[i], reverse=True)  # stable, like sorted()
-    return dict(emd=np.asarray(emd), alphaclip=np.asarray(aclip), pvv=np.asarray(pvv), pvt=np.asarray(pvt),
-                emd_scaled=np.asarray(emd_s), alphaclip_scaled=np.asarray(acl_s), score=np.asarray(score),
-                order=np.asarray(order), feats=feats, text=text)
+    return dict(emd=np.asarray(emd), alphaclip=np.asarray(aclip, dtype=np.float64), pvv=np.asarray(pvv), pvt=np.asarray(pvt),
+                emd_scaled=np.asarray(emd_s), alphaclip_scaled=np.asarray(acl_s, dtype=np.float64), score=np.asarray(score),
+                order=np.asarray(order))
 
 
 def fmm_merge(mask_proposals, score: np.ndarray, order: np.ndarray, *, static_threshold: float = 0.55,
@@ -276,6 +294,11 @@ def fmm_merge(mask_proposals, score: np.ndarray, order: np.ndarray, *, static_th
 # ----------------------------------------------------------------------------
 # whole ranking path + evaluation
 # ----------------------------------------------------------------------------
+def alphaclip_prompt(name: str, description: str) -> List[str]:
+    """/root/reference/mars/MARS.py:85-89."""
+    return [f"a {name}."] if description == "" else [f"a {name}, {description}."]
+
+
 def mars_predict(models: dict, batch: dict, tokens: dict, *, vva_thr=0.8, vva_last_n=24, vta_thr=0.4,
                  vta_last_n=8, alpha=0.85, static_threshold=0.55, dynamic_threshold=0.95, aclip_batch=8):
     """/root/reference/mars/MARS.py:59-102 with the text retriever replaced by fixed
