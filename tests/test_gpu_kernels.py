@@ -484,9 +484,11 @@ def test_rank_merge_matches_oracle_arithmetic(pkg, cuda):
         pvv = 0.85 * (svv.astype(np.float64) / (1e-7 + cnt)) + 0.15 * cov
         pvt = 0.85 * (svt.astype(np.float64) / (1e-7 + cnt)) + 0.15 * cov
         es = (emd - emd.min()) / (1e-7 + emd.max() - emd.min())
-        a64 = aclip.astype(np.float64)
-        as_ = (a64 - a64.min()) / (1e-7 + a64.max() - a64.min())
-        want = (es + as_ + pvv + pvt) / 4
+        # the AlphaCLIP min-max stays float32, as the reference's numpy expression does (float32 entries,
+        # Python-float epsilon: FilteringMergingModule.py:128-132)
+        as_ = (aclip - aclip.min()) / (np.float32(1e-7) + aclip.max() - aclip.min())
+        assert as_.dtype == np.float32
+        want = (es + as_.astype(np.float64) + pvv + pvt) / 4
         assert np.abs(score.cpu().numpy() - want).max() < 1e-12
         want_order = sorted(range(N), key=lambda i: score.cpu().numpy()[i], reverse=True)
         assert order.cpu().tolist() == want_order
