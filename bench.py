@@ -9,6 +9,11 @@ DINOv2-L/14 reg4 @518, CLIP ViT-B/16, AlphaCLIP ViT-L/14@336, 64 proposals, bf16
 on seeded synthetic weights and episodes that are resident in HBM before the clock starts.
 Episodes shard round-robin over ranks (weak scaling: K episodes per GPU); the only collective
 is the sum of the [2, nclass] intersection/union buffers.
+
+Launching: under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) this file
+is one rank.  Called bare with --gpus N > 1 it starts the N ranks itself, as fresh child processes, before
+anything touches the GPU, and exits with the first non-zero child status.  A world size that differs from
+--gpus is an error, never a silently smaller run.
 """
 from __future__ import annotations
 
@@ -37,6 +42,69 @@ RING_KERNELS = {3: "gemm_tn_ring_kernel<bf16, *, 2, 4, 8, 4, 2, 3> (256x256 tile
                 11: "gemm_tn_ring_kernel<bf16, *, 2, 2, 4, 4, 2, 4, true> (128x128 tile, pair fills)"}
 
 
+def rank_episodes(rank: int, world: int, per_rank: int):
+    """Global indices of the episodes rank ``rank`` of ``world`` runs, in order: index k * world + rank
+    for k < per_rank.  The ranks' lists partition range(per_rank * world) (weak scaling: per_rank each)."""
+    if not (0 <= rank < world and per_rank >= 0):
+        raise ValueError(f"bad shard: rank {rank} of {world}, {per_rank} episodes per rank")
+    return [k * world + rank for k in range(per_rank)]
+
+
+def reduce_over_ranks(meter, elapsed: float, device, world: int) -> float:
+    """The run's only collectives: SUM of the meter's [2, nclass] count buffers, MAX of the ranks' elapsed
+    seconds (returned).  With one rank nothing is exchanged."""
+    import torch.distributed as dist
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        meter.all_reduce()
+    return float(el)
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start ``n`` ranks of this file as child processes (this process has not touched the GPU and never
+    does) with the rendezvous variables a launcher would set; returns the first non-zero exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def host_cores() -> int:
+    """Cores this process may use: its affinity mask, capped by OMP_NUM_THREADS when the box sets one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    cap = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(n, cap) if cap > 0 else n)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build_args(device, dtype):
     return types.SimpleNamespace(
         input_size=SIZE, num_regs=4, dino_backbone="vit_large", vta_backbone="ViT-B/16", alphaclip_backbone="ViT-L/14@336px",
@@ -52,13 +120,14 @@ def state_dicts(pkg, seed=0):
                 alphaclip=synth.clip_state_dict(synth.CLIP_ARCHS["ViT-L/14@336px"], seed, alpha=True))
 
 
-def cpu_baseline(pkg, sds, sample_props=4):
-    """The CPU oracle on a bounded sample of the same workload: both DINOv2-L passes, the CLIP
-    pass with GradCAM and refinement, and `sample_props` of the 64 proposals through AlphaCLIP +
-    EMD; the per-proposal part is scaled to 64."""
+def cpu_baseline(pkg, sds, warm_props=2):
+    """The CPU oracle on ONE whole episode of the same workload, measured, not scaled: both DINOv2-L passes,
+    the CLIP pass with GradCAM and refinement, and all 64 proposals through AlphaCLIP + exact EMD + ranking, on
+    every core this process may use.  A short pass (the towers and ``warm_props`` proposals) runs first so
+    that thread pools and pages are warm.  Runs after the timed GPU region, on rank 0 of a one-GPU run only."""
     from oracle import pipeline as opipe
     synth = pkg.synth
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     d, c, a = synth.dino_cfg("vit_large", SIZE), synth.CLIP_ARCHS["ViT-B/16"], synth.CLIP_ARCHS["ViT-L/14@336px"]
     models = dict(
@@ -70,37 +139,49 @@ def cpu_baseline(pkg, sds, sample_props=4):
     ep = synth.make_episode(1000 * FOLD, size=SIZE, nshot=1, nprop=NPROP, fold=FOLD)
     tok = dict(fg=synth.tokenize(["a photo of object."]), bg=synth.tokenize(["a photo without object."]),
                alphaclip=synth.tokenize(["a object."]))
-    with torch.no_grad():
+
+    def one_pass(nprop):
         t0 = time.time()
-        v = opipe.vva_compute(models["dino_sd"], models["dino_kw"], ep["support_imgs"], ep["support_masks"], ep["query_img"])
+        with torch.no_grad():
+            v = opipe.vva_compute(models["dino_sd"], models["dino_kw"], ep["support_imgs"], ep["support_masks"], ep["query_img"])
         t1 = time.time()
-    t = opipe.vta_compute(models["clip_sd"], models["clip_kw"], ep["query_img"], tok["fg"], tok["bg"])
-    t2 = time.time()
-    g = v["vva"].shape[0]
-    vta = torch.nn.functional.interpolate(t["vta"][None, None], (g, g), mode="nearest")[0, 0]
-    with torch.no_grad():
-        opipe.fmm_scores(models["aclip_sd"], models["aclip_kw"], ep["query_img"], ep["mask_proposals"][:sample_props],
-                         ep["support_masks"], v["cost"], g, v["vva"], opipe.minmax(vta), tok["alphaclip"], batch=sample_props)
-    t3 = time.time()
-    per_query = (t1 - t0) + (t2 - t1) + (t3 - t2) * (NPROP / sample_props)
-    return {"value": 1.0 / per_query, "unit": "query images/s", "cores": cores, "kind": "port",
-            "sample": f"1 episode of the same workload: DINOv2-L x2 {t1 - t0:.1f}s + CLIP-B/16 GradCAM {t2 - t1:.1f}s measured in "
-                      f"full, {sample_props} of {NPROP} proposals through AlphaCLIP-L/14@336 + exact EMD {t3 - t2:.1f}s scaled x"
-                      f"{NPROP // sample_props}; fp32 torch CPU oracle"}
+        t = opipe.vta_compute(models["clip_sd"], models["clip_kw"], ep["query_img"], tok["fg"], tok["bg"])   # GradCAM needs autograd
+        t2 = time.time()
+        g = v["vva"].shape[0]
+        vta = opipe.minmax(torch.nn.functional.interpolate(t["vta"][None, None], (g, g), mode="nearest")[0, 0])
+        props = ep["mask_proposals"][:nprop]
+        with torch.no_grad():
+            s = opipe.fmm_scores(models["aclip_sd"], models["aclip_kw"], ep["query_img"], props, ep["support_masks"], v["cost"], g,
+                                 v["vva"], vta, tok["alphaclip"], batch=min(8, nprop))
+        mask, _ = opipe.fmm_merge(props, s["score"], s["order"])
+        opipe.classify_prediction(mask, ep["query_mask"][0])
+        t3 = time.time()
+        return t1 - t0, t2 - t1, t3 - t2
+
+    one_pass(warm_props)
+    dino_s, clip_s, rank_s = one_pass(NPROP)
+    per_query = dino_s + clip_s + rank_s
+    return {"value": 1.0 / per_query, "unit": "query images/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "seconds_per_query": per_query,
+            "sample": f"1 whole episode of the same workload after a warm-up pass, nothing scaled: DINOv2-L x2 {dino_s:.1f}s + "
+                      f"CLIP-B/16 GradCAM and refinement {clip_s:.1f}s + all {NPROP} proposals through AlphaCLIP-L/14@336, exact EMD, "
+                      f"ranking, merge and IoU {rank_s:.1f}s; fp32 torch CPU oracle on {cores} threads"}
 
 
 def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 counter passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs, FETCH_SIZE doubled for gfx950; see tools/pmc_traffic.py), or None."""
+    """HBM-side bytes per GEMM launch from the COMMITTED rocprofv3 counter passes under profiles/ (FETCH_SIZE and
+    WRITE_SIZE, separate runs, FETCH_SIZE doubled for gfx950; see tools/pmc_traffic.py), or (None, None).  Counters
+    cannot be read from inside the run that prints the line, so the figure is a stored one and the line says
+    which file it came from (``traffic_source``)."""
     import glob
     import re
     tag = lambda p: [int(x) for x in re.findall(r"\d+", os.path.basename(p))]     # r1_v10 after r1_v9  # noqa: E731
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=tag, reverse=True):   # newest tag first
         try:
-            return float(json.load(open(path))["bytes_per_launch"])
+            return float(json.load(open(path))["bytes_per_launch"]), "stored profile " + os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
 
 
 def main():
@@ -114,10 +195,19 @@ def main():
                     help="side measurement: 8-bit float operands in the AlphaCLIP attention (not the headline configuration)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks here, before anything in this process touches the GPU
+        visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if visible < args.gpus:
+            sys.exit(f"--gpus {args.gpus} but only {visible} GPU(s) are visible")
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     import torch.distributed as dist
@@ -138,11 +228,10 @@ def main():
     dataset = types.SimpleNamespace(benchmark="coco", class_ids=[FOLD + 4 * i for i in range(20)])
     meter = AverageMeter(dataset, device=dev)
 
-    # this rank's episodes: global index e = k * world + rank, seed = 1000*fold + e, resident in HBM
+    # this rank's episodes (seed = 1000*fold + global index), resident in HBM before the clock starts
     total = args.steps + args.warmup
     eps = []
-    for k in range(total):
-        e = k * world + rank
+    for e in rank_episodes(rank, world, total):
         ep = pkg.synth.make_episode(1000 * FOLD + e, size=SIZE, nshot=1, nprop=NPROP, fold=FOLD)
         eps.append({k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in ep.items()})
 
@@ -173,11 +262,8 @@ def main():
     elapsed = time.perf_counter() - t0
     prof, pkg.ops.GEMM_PROFILE = pkg.ops.GEMM_PROFILE or [], None
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        meter.all_reduce()
-    elapsed = float(el)
+    elapsed = reduce_over_ranks(meter, elapsed, dev, world)
+    ranks_joined = dist.get_world_size() if world > 1 else 1          # what RCCL itself reports
     miou, fb_iou, _ = meter.compute_iou()
 
     if rank == 0:
@@ -197,6 +283,8 @@ def main():
         all_gemm = {"achieved": sum(t[1] for t in timed) / (ms_all * 1e-3) / 1e12 if ms_all > 0 else 0.0, "launches": len(timed),
                     "share_of_step": ms_all / (elapsed / args.steps * 1e3)}
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        # HBM-side bytes were counted (stored counter passes) on the pair-fill 256x256 kernel only
+        traffic, traffic_src = pmc_traffic() if args.dtype == "bf16" and dom_variant == 8 else (None, None)
         out = {
             "metric": "query images/sec", "value": args.steps * world / elapsed, "unit": "query images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -204,10 +292,10 @@ def main():
             "dtype": args.dtype + ("+fp8-attention" if args.fp8_attention else ""), "data": "synthetic",
             "config": {"workload": "COCO-20i fold0 1-shot, DINOv2-L/14-reg4@518 + CLIP ViT-B/16 GradCAM + AlphaCLIP ViT-L/14@336, "
                                    "64 proposals, exact EMD, rank+merge+IoU (BASELINE configs[1])",
-                       "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}"},
+                       "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}", "rccl_ranks": ranks_joined},
             "miou": float(miou), "fb_iou": float(fb_iou),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic() if args.dtype == "bf16" and dom_variant == 8 else None,   # counted on that kernel
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": RING_KERNELS.get(dom_variant, f"gemm variant {dom_variant}").replace(
                              "<bf16,", "<bf16," if args.dtype == "bf16" else "<f32,"),
                          "launches": len(dom), "avg_launch_us": ms * 1e3 / max(len(dom), 1), "sampled_steps": 1,
