@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - every device buffer is allocated by the caller; the library owns no device memory
- *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), no sync
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), no sync; the stream and
+ *     every device pointer must belong to the device that is current in the calling thread
+ *   - no state besides the two GEMM tuning hooks (process-wide relaxed atomics; see their comments)
  *   - return 0 on success, negative on error; marship_last_error() gives the text
  *   - "TN GEMM": C[M,N] = A[M,K] * B[N,K]^T, both operands K-contiguous
  *   - dtype codes: 0 = float32, 1 = bfloat16
@@ -51,7 +53,9 @@ int marship_gemm(const MarsGemm* g, void* stream);
  * one. 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
  * 3 = LDS-DMA ring 256x256, 4 = chosen by shape (default), 5 = ring 256x128, 6 = ring 128x128,
  * 7 = ring 64x128, 8 = ring 256x256 with pair fills, 9 / 10 / 11 = 128x128 (eight slots), 64x128 (six slots),
- * 128x128 (four slots) with pair fills. */
+ * 128x128 (four slots) with pair fills.  Process-wide: every later marship_gemm of every thread reads it (a
+ * relaxed atomic: no data race, but no ordering with products other threads are launching) - set it at
+ * start-up or while no other thread launches products.  The same holds for marship_set_gemm_split. */
 int marship_set_gemm_variant(int variant);
 /* The variant marship_gemm would run for this product (5, 6, 7, 8, 10 or 11 under "chosen by shape"); used by
  * the benchmark to attribute launch times to kernels.  No reference counterpart. */

@@ -15,6 +15,7 @@
 // one barrier per k-tile.  Chunk c of row r is stored at chunk c ^ ((r >> 1) & 7) so the
 // 16 rows a ds_read_b128 lane group touches land on 16 distinct 16-byte bank slots.
 // Out-of-range rows are clamped on the source address (results never stored).
+#include <atomic>
 #include "common.h"
 #include "../../include/mars_hip.h"
 
@@ -160,7 +161,10 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(MarsGemm g) {
 
 void mars_gemm_glds_launch(const MarsGemm& g, hipStream_t s, int variant);
 void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape);
-static int g_gemm_variant = 4;
+// The two tuning hooks below set process-wide state that every later marship_gemm call of every thread reads.
+// They are relaxed atomics: reading them while another thread sets them is not a data race, but a setter is not
+// ordered with products other threads are launching - set them at start-up, or while nobody else launches.
+static std::atomic<int> g_gemm_variant{4};
 
 // Tuning hook: 0 = register-staged 128x128, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
 // 3 = LDS-DMA ring 256x256, 4 = choose by shape (default), 5 = LDS-DMA ring 256x128,
@@ -168,24 +172,19 @@ static int g_gemm_variant = 4;
 // 9 = 128x128 with pair fills and eight slots, 10 = 64x128 with pair fills and six slots,
 // 11 = 128x128 with pair fills and four slots.
 extern "C" int marship_set_gemm_variant(int v) {
-    const int old = g_gemm_variant;
-    if (v >= 0 && v <= 11) g_gemm_variant = v;
-    return old;
+    if (v >= 0 && v <= 11) return g_gemm_variant.exchange(v, std::memory_order_relaxed);
+    return g_gemm_variant.load(std::memory_order_relaxed);
 }
 
 // Tuning hook: 1 (default) lets "choose by shape" cut a tall product into two launches when the tiles of one
 // launch would leave most of the chip idle in their last round; 0 keeps every product in one launch.
-static int g_gemm_split = 1;
-extern "C" int marship_set_gemm_split(int on) {
-    const int old = g_gemm_split;
-    g_gemm_split = on != 0;
-    return old;
-}
+static std::atomic<int> g_gemm_split{1};
+extern "C" int marship_set_gemm_split(int on) { return g_gemm_split.exchange(on != 0, std::memory_order_relaxed); }
 
 // the kernel variant the launch policy picks for a product (the variant set by the tuning hook, or, for
 // "choose by shape", the ring shape: 5, 6, 7, 8, 10 or 11)
 static int pick_variant(const MarsGemm* g) {
-    int v = g_gemm_variant;
+    int v = g_gemm_variant.load(std::memory_order_relaxed);
     if (v == 4) {
         // the 256 x 128 ring shape needs about a full wave of workgroups to pay off; below that
         // the 128 x 128 shape spreads the product over more CUs (bf16: with pair fills)
@@ -208,7 +207,8 @@ static int pick_variant(const MarsGemm* g) {
 }
 
 static int cu_count() {
-    static int n = 0;
+    static std::atomic<int> cached{0};
+    int n = cached.load(std::memory_order_relaxed);
     if (n == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
@@ -216,6 +216,7 @@ static int cu_count() {
             n = cus;
         else
             n = 256;
+        cached.store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -225,7 +226,7 @@ static int cu_count() {
 // the last round is less than 0.6 full (the AlphaCLIP projection and FC2: 2.27 rounds) the rows of the full
 // rounds go out as one launch and the rest as a launch of their own, which the policy then gives a smaller tile.
 static int split_rows(const MarsGemm* g, int v) {
-    if (!g_gemm_split || g_gemm_variant != 4 || g->nb0 * g->nb1 != 1 || v != 8) return g->M;
+    if (!g_gemm_split.load(std::memory_order_relaxed) || g_gemm_variant.load(std::memory_order_relaxed) != 4 || g->nb0 * g->nb1 != 1 || v != 8) return g->M;
     const int bn = v == 8 ? 256 : 128, slots = cu_count() * (v == 8 ? 1 : 2);
     const int64_t ntm = (g->M + 255) / 256, ntn = (g->N + bn - 1) / bn, tiles = ntm * ntn;
     const int64_t full = tiles / slots, rem = tiles % slots;
@@ -262,7 +263,7 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     const int ntm = (g->M + BM - 1) / BM, ntn = (g->N + BN - 1) / BN;
     dim3 grid(ntm * ntn, g->nb0 * g->nb1), block(THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (g_gemm_variant != 0) {
+    if (g_gemm_variant.load(std::memory_order_relaxed) != 0) {
         const int v = pick_variant(g);
         const int rows = split_rows(g, v);
         if (rows < g->M) {

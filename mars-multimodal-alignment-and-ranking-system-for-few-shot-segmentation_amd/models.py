@@ -129,18 +129,32 @@ class Tower:
 
     # ---- one block ----
     def block_forward(self, x: torch.Tensor, blk: Block, *, causal=False, need_probs=False, mean_acc=None, keep=None):
-        """x f32 [B,T,D], updated in place.  ``keep`` (dict) receives intermediates for the CAM backward."""
+        """x f32 [B,T,D], updated in place.  ``keep`` (dict) receives the intermediates the CAM backward needs:
+        they are written to buffers of their own in this tower's workspace (valid until its next call with
+        ``keep`` and the same shape), nothing is copied."""
         B, T, D = x.shape
         w = self.ws(B, T, blk.hidden_alloc)
         x2 = x.view(B * T, D)
+        if keep is not None:
+            assert blk.ffn == "mlp"
+            k = w.get("keep")
+            if k is None:
+                z = lambda n, dt: torch.zeros(B * T, n, dtype=dt, device=self.device)     # noqa: E731
+                k = w["keep"] = dict(ln1=z(D, self.dtype), ln2=z(D, self.dtype), x1=z(D, torch.float32), pre=z(blk.fc1.N, self.dtype))
+            ops.layernorm(x2, blk.ln1.w, blk.ln1.b, k["ln1"], blk.ln1.eps)
+            ops.linear(k["ln1"], blk.qkv.w, w["qkv"], bias=blk.qkv.b)
+            P = self.attention(w, B, T, causal=causal, need_probs=need_probs, mean_acc=mean_acc)
+            ops.linear(w["ao"], blk.proj.w, k["x1"], bias=blk.proj.b, gamma=blk.ls1, residual=x2)      # x1 = x + attn
+            ops.layernorm(k["x1"], blk.ln2.w, blk.ln2.b, k["ln2"], blk.ln2.eps)
+            ops.linear(k["ln2"], blk.fc1.w, k["pre"], bias=blk.fc1.b)                                   # before the activation
+            ops.linear(k["ln2"], blk.fc1.w, w["hid"], bias=blk.fc1.b, act=blk.act)
+            ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, residual=k["x1"])
+            keep.update(ln1=k["ln1"], qkv=w["qkv"], ao=w["ao"], x1=k["x1"], ln2=k["ln2"], pre=k["pre"])
+            return P
         ops.layernorm(x2, blk.ln1.w, blk.ln1.b, w["xn"], blk.ln1.eps)
         ops.linear(w["xn"], blk.qkv.w, w["qkv"], bias=blk.qkv.b)
         P = self.attention(w, B, T, causal=causal, need_probs=need_probs, mean_acc=mean_acc)
-        if keep is not None:
-            keep["ln1"] = w["xn"].clone(); keep["qkv"] = w["qkv"].clone(); keep["ao"] = w["ao"].clone()
         ops.linear(w["ao"], blk.proj.w, x2, bias=blk.proj.b, gamma=blk.ls1, residual=x2)
-        if keep is not None:
-            keep["x1"] = x2.clone()
         ops.layernorm(x2, blk.ln2.w, blk.ln2.b, w["xn"], blk.ln2.eps)
         if blk.ffn == "swiglu":
             ops.linear(w["xn"], blk.fc1.w, w["hid"], bias=blk.fc1.b)          # [M, 2*hidden]
@@ -150,10 +164,6 @@ class Tower:
             ops.swiglu(w["hid"], g)                                            # pad columns stay zero
             ops.linear(g, blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, residual=x2)
         else:
-            if keep is not None:
-                pre = w.setdefault("pre", torch.zeros(B * T, blk.fc1.N, dtype=self.dtype, device=self.device))
-                ops.linear(w["xn"], blk.fc1.w, pre, bias=blk.fc1.b)
-                keep["ln2"] = w["xn"].clone(); keep["pre"] = pre.clone()
             ops.linear(w["xn"], blk.fc1.w, w["hid"], bias=blk.fc1.b, act=blk.act)
             ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, residual=x2)
         return P
@@ -370,6 +380,7 @@ class CLIP(_TextTower):
         self.logit_scale_exp = float(sd["logit_scale"].float().exp())
         self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
         self._cols: Dict[int, torch.Tensor] = {}
+        self._cam_bufs: Dict[int, dict] = {}
         self.visual = _Visual()
         self.visual.patch_size = p
         self.visual.input_resolution = cfg.image_resolution
@@ -434,84 +445,96 @@ class CLIP(_TextTower):
         """forward_last_layer (clip/model.py:501-524) on the LND tokens ``encode_image`` returned: last
         block in f32, ln_post, patch-token mean, projection, softmax over the {fg, bg} text pair.
         Returns (logits [B,2], head-averaged attention [B,T,T])."""
-        return self._last_layer(image_features.permute(1, 0, 2).contiguous().float(), text_features)
+        X = image_features.permute(1, 0, 2).contiguous().float()
+        B, T, _ = X.shape
+        logits, P = self._last_layer(X, text_features)
+        return logits, P.view(B, self.cfg.vision_heads, T, -1)[..., :T].mean(dim=1)
 
     def _last_layer(self, X, text_features, mean_attn=None, keep=None):
-        """Same on batch-major tokens X f32 [B,T,D] (modified in place)."""
+        """Same on batch-major tokens X f32 [B,T,D] (modified in place).  Returns (logits [B,2], the block's
+        probabilities [B*H, T, Tp]); the head average is left to the one caller that hands it out."""
         B, T, D = X.shape
         blk = self.vtower.blocks[-1]
         P = self.vtower32.block_forward(X, blk, need_probs=True, mean_acc=mean_attn, keep=keep)
-        H = self.cfg.vision_heads
-        attn = P.view(B, H, T, -1)[..., :T].mean(dim=1)
-        y = torch.empty(B * T, D, dtype=torch.float32, device=self.device)
-        ops.layernorm(X.view(B * T, D), self.ln_post.w, self.ln_post.b, y, self.ln_post.eps)
+        c = self._cam_ws(T)
+        ops.layernorm(X.view(B * T, D), self.ln_post.w, self.ln_post.b, c["y"], self.ln_post.eps)
         logits = torch.empty(B, 2, dtype=torch.float32, device=self.device)
-        f = torch.empty(D, dtype=torch.float32, device=self.device)
-        df = torch.empty(D, dtype=torch.float32, device=self.device)
         assert B == 1 and text_features.shape[0] == 2, "the CAM head is written for one image and the {fg, bg} text pair"
-        ops.col_mean(y, 1, T, f)
-        ops.cam_head(f, self.vproj, text_features.float().contiguous(), self.logit_scale_exp, logits, df)
+        ops.col_mean(c["y"], 1, T, c["f"])
+        ops.cam_head(c["f"], self.vproj, text_features.float().contiguous(), self.logit_scale_exp, logits, c["df"])
         if keep is not None:
-            keep.update(x2=X.view(B * T, D), df=df, P=P, T=T)
-        return logits, attn
+            keep.update(x2=X.view(B * T, D), df=c["df"], P=P, T=T)
+        return logits, P
+
+    def _cam_ws(self, T: int) -> dict:
+        """Buffers of the CAM head and its backward for a T-token image, allocated (and zeroed) once: every
+        kernel below writes the valid [.., T] part of its output only, so the pad columns that later products
+        contract over stay zero from one call to the next."""
+        c = self._cam_bufs.get(T)
+        if c is None:
+            D, H, Tp = self.cfg.vision_width, self.cfg.vision_heads, _pad_to(T, 64)
+            z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=self.device)     # noqa: E731
+            c = self._cam_bufs[T] = dict(
+                y=z(T, D), f=z(D), df=z(D), dx2=z(T, D), dh=z(T, 4 * D), dm=z(T, D), dx1=z(T, D), do=z(T, D),
+                dP=z(H, T, Tp), dS=z(H, T, Tp), dqkv=z(T, 3 * D), PT=z(H, Tp, Tp), dOT=z(H, 64, Tp), KT=z(H, 64, Tp),
+                dST=z(H, Tp, Tp), QT=z(H, 64, Tp), grad=z(T, D), wgt=z(D))
+        return c
 
     def gradcam(self, X: torch.Tensor, text_features: torch.Tensor, mean_attn=None):
         """Softmax-GradCAM of the last block w.r.t. its ln_1 output (pytorch_grad_cam/base_cam.py:62-118,
         grad_cam.py:16-23) by explicit backward kernels.  X f32 [1,T,D] = output of encode_image_tokens.
         Returns (cam [G,G] min-max scaled twice, logits [1,2])."""
         keep: dict = {}
-        logits, _ = self._last_layer(X.clone(), text_features, mean_attn=mean_attn, keep=keep)
+        logits, _ = self._last_layer(X, text_features, mean_attn=mean_attn, keep=keep)      # X is consumed (updated in place)
         T, D, H = keep["T"], self.cfg.vision_width, self.cfg.vision_heads
-        dev = self.device
         blk = self.vtower.blocks[-1]
         Tp = _pad_to(T, 64)
-        f32 = dict(dtype=torch.float32, device=dev)
+        c = self._cam_ws(T)
         # ln_post backward: dy = df/(T-1) on patch rows, 0 on the class row
-        dx2 = torch.empty(T, D, **f32)
+        dx2 = c["dx2"]
         ops.layernorm_bwd(keep["x2"], self.ln_post.w, keep["df"], 0, 1.0 / (T - 1), 1, None, dx2, self.ln_post.eps)
         # MLP backward
-        dh = torch.empty(T, 4 * D, **f32)
+        dh = c["dh"]
         ops.linear(dx2, self.last_T["c_proj"], dh)                      # dh = dx2 @ W_proj
         ops.quickgelu_bwd(dh, keep["pre"], dh)
-        dm = torch.empty(T, D, **f32)
+        dm = c["dm"]
         ops.linear(dh, self.last_T["c_fc"], dm)                         # dm = dpre @ W_fc
-        dx1 = torch.empty(T, D, **f32)
+        dx1 = c["dx1"]
         ops.layernorm_bwd(keep["x1"], blk.ln2.w, dm, D, 1.0, 0, dx2, dx1, blk.ln2.eps)
         # attention backward
-        do = torch.empty(T, D, **f32)
+        do = c["do"]
         ops.linear(dx1, self.last_T["out_proj"], do)                    # dO = dx1 @ W_out
         qkv, P = keep["qkv"], keep["P"]                                 # [T,3D], [H,T,Tp]
-        dP = torch.zeros(H, T, Tp, **f32)
+        dP = c["dP"]
         ops.gemm(do, qkv, dP, T, T, 64, lda=D, ldb=3 * D, ldc=Tp, b_off=2 * D, nb0=1, nb1=H, sA=(0, 64), sB=(0, 64),
                  sC=(0, T * Tp))                                        # dP = dO_h V_h^T
-        dS = torch.zeros(H, T, Tp, **f32)
+        dS = c["dS"]
         ops.softmax_bwd(P, dP, dS, Tp, H, T, 0.125)                     # includes the 1/8 of q.k/8
-        dqkv = torch.zeros(T, 3 * D, **f32)
-        PT = torch.zeros(H, Tp, Tp, **f32)
+        dqkv, PT = c["dqkv"], c["PT"]
         ops.transpose_raw(P, 0, Tp, (0, T * Tp), PT, 0, Tp, (0, Tp * Tp), T, T, 1, H)
-        dOT = torch.zeros(H, 64, Tp, **f32)
+        dOT = c["dOT"]
         ops.transpose_raw(do, 0, D, (0, 64), dOT, 0, Tp, (0, 64 * Tp), T, 64, 1, H)
         # dV_h[key, d] = sum_q P[q,key] dO[q,d]
         ops.gemm(PT, dOT, dqkv, T, 64, Tp, lda=Tp, ldb=Tp, ldc=3 * D, c_off=2 * D, nb0=1, nb1=H, sA=(0, Tp * Tp),
                  sB=(0, 64 * Tp), sC=(0, 64))
-        KT_ = torch.zeros(H, 64, Tp, **f32)
+        KT_ = c["KT"]
         ops.transpose_raw(qkv, D, 3 * D, (0, 64), KT_, 0, Tp, (0, 64 * Tp), T, 64, 1, H)
         # dQ_h = dS_h K_h
         ops.gemm(dS, KT_, dqkv, T, 64, Tp, lda=Tp, ldb=Tp, ldc=3 * D, c_off=0, nb0=1, nb1=H, sA=(0, T * Tp),
                  sB=(0, 64 * Tp), sC=(0, 64))
-        dST = torch.zeros(H, Tp, Tp, **f32)
+        dST = c["dST"]
         ops.transpose_raw(dS, 0, Tp, (0, T * Tp), dST, 0, Tp, (0, Tp * Tp), T, T, 1, H)
-        QT = torch.zeros(H, 64, Tp, **f32)
+        QT = c["QT"]
         ops.transpose_raw(qkv, 0, 3 * D, (0, 64), QT, 0, Tp, (0, 64 * Tp), T, 64, 1, H)
         # dK_h = dS_h^T Q_h
         ops.gemm(dST, QT, dqkv, T, 64, Tp, lda=Tp, ldb=Tp, ldc=3 * D, c_off=D, nb0=1, nb1=H, sA=(0, Tp * Tp),
                  sB=(0, 64 * Tp), sC=(0, 64))
-        grad = torch.empty(T, D, **f32)
+        grad = c["grad"]
         ops.linear(dqkv, self.last_T["in_proj"], grad)                  # d ln1 = dqkv @ W_in
         # channel weights = mean gradient over the patch tokens; cam = relu(sum_c w_c act_c)
-        wgt = torch.empty(D, **f32)
+        wgt = c["wgt"]
         ops.col_mean(grad, 1, T, wgt)
-        cam = torch.empty(T - 1, **f32)
+        cam = torch.empty(T - 1, dtype=torch.float32, device=self.device)
         ops.cam_rows(keep["ln1"], wgt, 1, T - 1, cam)
         ops.minmax(cam, cam)
         ops.minmax(cam, cam)
