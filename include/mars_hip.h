@@ -8,7 +8,8 @@
  * ctypes with tensor.data_ptr() values.
  *
  * Conventions
- *   - every device buffer is allocated by the caller; the library owns no device memory
+ *   - every device buffer is allocated by the caller; the library owns no device memory apart from
+ *     the 2 MiB static array of marship_vva_prior_static
  *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), no sync; the stream and
  *     every device pointer must belong to the device that is current in the calling thread
  *   - no state besides the two GEMM tuning hooks (process-wide relaxed atomics; see their comments)
@@ -129,6 +130,15 @@ int marship_l2norm_rows(const float* x, int64_t x_bstride, int64_t x_stride, int
  * S f32 [R, ldS] (R = ns*P), fg u8 [R]; ws f32 workspace of 4*chunks*P floats; out f32 [P]. */
 int marship_vva_prior(const float* S, int64_t ldS, const uint8_t* fg, int R, int P, float* ws,
                       int chunks, float* out, void* stream);
+/* marship_vva_prior for callers that cannot allocate device memory or bring a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): no counterpart in the reference.
+ * Same kernels and results as marship_vva_prior with chunks = 32; the partial sums live in a 2 MiB
+ * file-scope device array of the library (one copy per GPU, held until the process ends), so P is limited
+ * to 4096 query patches and a larger P is rejected with an error.  Calls no hipMalloc / hipFree.  The first
+ * call on a device resolves the array's address there (make that call outside a capture).  All calls on one
+ * GPU share the array: calls that overlap on one GPU (two streams, two threads) race; order them. */
+int marship_vva_prior_static(const float* S, int64_t ldS, const uint8_t* fg, int R, int P, float* out,
+                             void* stream);
 /* (x - min) / (1e-7 + max - min) over n elements (single block). */
 int marship_minmax(const float* x, float* y, int n, void* stream);
 /* Box mask B of the thresholded prior (PriorInformationRefinementModule.py:53-65,91-122):

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "../../include/mars_hip.h"
 #include <limits.h>
+#include <mutex>
 
 namespace {
 
@@ -496,6 +497,49 @@ extern "C" int marship_vva_prior(const float* S, int64_t ldS, const uint8_t* fg,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(vva_partial_kernel, dim3((P + 255) / 256, chunks), dim3(256), 0, s, S, ldS, fg, R, P, chunks, ws);
     hipLaunchKernelGGL(vva_final_kernel, dim3(1), dim3(1024), 0, s, ws, fg, R, P, chunks, out);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the same prior for callers that cannot allocate: the partial sums live in a file-scope device array
+constexpr int VVA_STATIC_CHUNKS = 32;
+constexpr int VVA_STATIC_MAX_P = 4096;       // query patches (a 64 x 64 grid; the path uses 37 x 37 = 1369)
+constexpr int VVA_STATIC_MAX_DEVICES = 64;
+// 4 x 32 x 4096 floats = 2 MiB on every GPU the library runs on, held until the process ends.  In host code this
+// name is only a handle for hipGetSymbolAddress: the kernels get the per-device address resolved from it.
+static __device__ __align__(256) float scratch[4 * VVA_STATIC_CHUNKS * VVA_STATIC_MAX_P];
+static float* g_scratch_ptr[VVA_STATIC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+extern "C" int marship_vva_prior_static(const float* S, int64_t ldS, const uint8_t* fg, int R, int P, float* out,
+                                        void* stream) {
+    MARS_CHECK(S && fg && out, "vva_prior_static: null pointer");
+    MARS_CHECK(R > 0 && P > 0 && ldS >= P, "vva_prior_static: bad shape");
+    MARS_CHECK(P <= VVA_STATIC_MAX_P, "vva_prior_static: %d query patches exceed the static scratch (at most %d)", P,
+               VVA_STATIC_MAX_P);
+    int dev = -1;
+    MARS_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < VVA_STATIC_MAX_DEVICES,
+               "vva_prior_static: no current device (or its index is beyond %d)", VVA_STATIC_MAX_DEVICES - 1);
+    float* ws = nullptr;
+    {
+        // every GPU holds its own copy of the array at its own address: resolved once per device, with that
+        // device current, on the first call there
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void* p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            MARS_CHECK(e == hipSuccess && p, "vva_prior_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                       hipGetErrorString(e));
+            g_scratch_ptr[dev] = (float*)p;
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    // the first kernel writes every partial the second one reads (all chunks, all P columns), so nothing has to
+    // start at zero; what a previous, larger call left behind lies beyond 4 * chunks * P and is never read
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(vva_partial_kernel, dim3((P + 255) / 256, VVA_STATIC_CHUNKS), dim3(256), 0, s, S, ldS, fg, R, P,
+                       VVA_STATIC_CHUNKS, ws);
+    hipLaunchKernelGGL(vva_final_kernel, dim3(1), dim3(1024), 0, s, ws, fg, R, P, VVA_STATIC_CHUNKS, out);
     MARS_LAUNCH_CHECK();
     return 0;
 }

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "marship_flash_attn_fp8": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "marship_l2norm_rows": [_P, _L, _L, _I, _I, _I, _I, _P, _L, _I, _P],
     "marship_vva_prior": [_P, _L, _P, _I, _I, _P, _I, _P, _P],
+    "marship_vva_prior_static": [_P, _L, _P, _I, _I, _P, _P],
     "marship_minmax": [_P, _P, _I, _P],
     "marship_box_mask": [_P, _I, _D, _P, _P],
     "marship_sinkhorn1": [_P, _L, _P, _L, _I, _P, _P],
