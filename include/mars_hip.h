@@ -104,21 +104,26 @@ int marship_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dty
 
 /* Fused attention for 64-wide heads on packed qkv [B*T, 3*D] (bf16):
  * O = softmax(q*scale k^T) v  (attention.py:54-60; alpha_clip/model.py:233-246), O bf16 [B*T, D];
- * lse f32 [B*H, T] receives log-sum-exp of the scaled scores (may be NULL). */
+ * lse f32 [B*H, T] receives log-sum-exp of the scaled scores (may be NULL).
+ * score_scale_log2 says what the stored queries still lack: the softmax is taken over 2^(score_scale_log2 * q.k).
+ * Raw queries: log2(e)/8 (the kernel multiplies its query fragments by it and rounds them to bf16 again).  Queries
+ * the caller has already scaled by log2(e)/8 - e.g. in the epilogue of the qkv product, one rounding instead of
+ * two - : exactly 1.0f, and the kernel uses them as they are.  The same parameter, with the same meaning, on the
+ * two entry points below. */
 int marship_flash_attn(const void* qkv, void* O, float* lse, int B, int T, int H, int causal,
-                       void* stream);
+                       float score_scale_log2, void* stream);
 /* The same attention with q, k, v and the probabilities quantised to 8-bit floats (OCP e4m3, one scale per image,
  * head and operand) and both contractions on the fp8 MFMA; f32 softmax and accumulation, no mask, no lse.  The caller
  * brings the workspace: q8, k8 [B*H*Tp*64] bytes, vt8 [B*H*64*Tp] bytes, scales [B*H*6] f32 (factors, then maxima), Tp = T rounded up to 32.
  * For the configuration that names an fp8 attention path; the reference (attention.py:54-60; alpha_clip/model.py:233-246)
  * has no such mode. */
 int marship_flash_attn_fp8(const void* qkv, void* O, int B, int T, int H, void* q8, void* k8, void* vt8, float* scales,
-                           int Tp, void* stream);
+                           int Tp, float score_scale_log2, void* stream);
 /* acc[i,j] += scale * sum_h exp(q_h[i].k_h[j]/8 - lse[h,i]) over the patch block starting at
  * token `off` of image 0 (bf16 qkv as above): the head/layer mean of the attention maps
  * (PriorInformationRefinementModule.py:31-45) without materialising them. */
 int marship_flash_attn_mean(const void* qkv, const float* lse, int T, int H, int off, int Pn,
-                            float scale, float* acc, int64_t ldacc, void* stream);
+                            float scale, float* acc, int64_t ldacc, float score_scale_log2, void* stream);
 
 /* ---- alignment / refinement ------------------------------------------------------ */
 /* F.normalize(p=2, dim=1) on gathered rows (VisualVisualAlignmentModule.py:122-125;

@@ -144,14 +144,14 @@ __device__ __forceinline__ void load_kv(KvFrag& f, const uint8_t* __restrict__ k
 
 __global__ __launch_bounds__(256) void flash_attn_fp8_kernel(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
                                                              const uint8_t* __restrict__ vt8, const float* __restrict__ scales,
-                                                             int T, int Tp, int H, __bf16* __restrict__ O) {
+                                                             int T, int Tp, int H, __bf16* __restrict__ O, float score_scale_log2) {
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB);
     if (q0 >= T) return;                                  // whole wave beyond the sequence (no barriers in this kernel)
     const float sq = scales[bh * 3 + 0], sk = scales[bh * 3 + 1], sv = scales[bh * 3 + 2];
-    const float sc = sq * sk * 0.125f * 1.44269504088896340736f;         // scores in the exp2 domain
+    const float sc = sq * sk * score_scale_log2;                            // scores in the exp2 domain
     const uint8_t* qb = q8 + (int64_t)bh * Tp * 64;
     const uint8_t* kb = k8 + (int64_t)bh * Tp * 64;
     const uint8_t* vb = vt8 + (int64_t)bh * 64 * Tp;
@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void flash_attn_fp8_kernel(const uint8_t* __re
 }  // namespace
 
 extern "C" int marship_flash_attn_fp8(const void* qkv, void* O, int B, int T, int H, void* q8, void* k8, void* vt8,
-                                      float* scales, int Tp, void* stream) {
+                                      float* scales, int Tp, float score_scale_log2, void* stream) {
     MARS_CHECK(qkv && O && q8 && k8 && vt8 && scales, "flash_attn_fp8: null pointer");
+    MARS_CHECK(score_scale_log2 > 0.f && score_scale_log2 < 1e6f, "flash_attn_fp8: score scale must be positive and finite");
     MARS_CHECK(B > 0 && T > 0 && H > 0 && Tp >= T && Tp % 32 == 0 && Tp - T < 32, "flash_attn_fp8: bad shape B=%d T=%d H=%d Tp=%d", B, T, H, Tp);
     MARS_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)O % 8) == 0 && ((uintptr_t)q8 % 8) == 0 && ((uintptr_t)k8 % 8) == 0 &&
                ((uintptr_t)vt8 % 4) == 0, "flash_attn_fp8: operands must be 8-byte aligned");
@@ -263,7 +264,7 @@ extern "C" int marship_flash_attn_fp8(const void* qkv, void* O, int B, int T, in
                        (uint8_t*)k8, (uint8_t*)vt8, scales);
     MARS_LAUNCH_CHECK();
     hipLaunchKernelGGL(flash_attn_fp8_kernel, dim3((T + 64 * QB - 1) / (64 * QB), B * H), dim3(256), 0, s, (const uint8_t*)q8, (const uint8_t*)k8,
-                       (const uint8_t*)vt8, scales, T, Tp, H, (__bf16*)O);
+                       (const uint8_t*)vt8, scales, T, Tp, H, (__bf16*)O, score_scale_log2);
     MARS_LAUNCH_CHECK();
     return 0;
 }

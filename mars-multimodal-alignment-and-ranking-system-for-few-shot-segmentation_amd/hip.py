@@ -48,9 +48,9 @@ _SIGNATURES = {
     "marship_attn_mean_accum": [_P, _L, _L, _I, _I, _I, _F, _P, _L, _I, _P],
     "marship_swiglu": [_P, _P, _L, _I, _I, _I, _P],
     "marship_cast": [_P, _P, _L, _I, _I, _P],
-    "marship_flash_attn": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "marship_flash_attn_mean": [_P, _P, _I, _I, _I, _I, _F, _P, _L, _P],
-    "marship_flash_attn_fp8": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "marship_flash_attn": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "marship_flash_attn_mean": [_P, _P, _I, _I, _I, _I, _F, _P, _L, _F, _P],
+    "marship_flash_attn_fp8": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P],
     "marship_l2norm_rows": [_P, _L, _L, _I, _I, _I, _I, _P, _L, _I, _P],
     "marship_vva_prior": [_P, _L, _P, _I, _I, _P, _I, _P, _P],
     "marship_vva_prior_static": [_P, _L, _P, _I, _I, _P, _P],

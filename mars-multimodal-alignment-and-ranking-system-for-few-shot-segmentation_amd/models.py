@@ -71,6 +71,7 @@ class Tower:
         self.blocks: List[Block] = []
         self._ws: Dict[Tuple[int, int, int], dict] = {}
         self.fp8_attention = False            # bf16 towers only: q, k, v and the probabilities as 8-bit floats
+        self._qscale: Optional[torch.Tensor] = None
 
     # ---- workspaces (allocated once per shape; pads stay zero) ----
     def ws(self, B: int, T: int, hidden: int) -> dict:
@@ -99,19 +100,35 @@ class Tower:
         return w
 
     # ---- attention ----
+    def uses_flash(self, need_probs: bool) -> bool:
+        return self.dtype == torch.bfloat16 and flash_enabled() and not need_probs
+
+    def query_scale(self, need_probs: bool) -> Optional[torch.Tensor]:
+        """Per-column factors for the epilogue of the qkv product when the fused attention will consume it: the
+        query columns come out multiplied by log2(e)/8 (rounded to bf16 once, from the f32 accumulator), so the
+        attention kernels take the scores in the exp2 domain straight from the matrix pipe."""
+        if not self.uses_flash(need_probs):
+            return None
+        if self._qscale is None:
+            g = torch.ones(3 * self.D, dtype=torch.float32, device=self.device)
+            g[: self.D] = ops.RAW_QUERY_SCALE_LOG2
+            self._qscale = g
+        return self._qscale
+
     def attention(self, w: dict, B: int, T: int, *, causal: bool, need_probs: bool, mean_acc=None):
         """qkv -> ao.  ``mean_acc`` = (acc [Pn,Pn] f32, off, Pn, scale): adds scale * sum over heads of the
-        probabilities of image 0 restricted to tokens off..off+Pn."""
+        probabilities of image 0 restricted to tokens off..off+Pn.  On the fused path the queries in ``qkv``
+        are the scaled ones of ``query_scale``; the unfused path takes raw queries."""
         D, H, Tp = self.D, self.H, w["Tp"]
-        use_flash = self.dtype == torch.bfloat16 and flash_enabled() and not need_probs
+        use_flash = self.uses_flash(need_probs)
         if use_flash and self.fp8_attention and not causal and mean_acc is None:
-            ops.flash_attn_fp8(w["qkv"], w["ao"], B, T, H, w.setdefault("fp8", {}))
+            ops.flash_attn_fp8(w["qkv"], w["ao"], B, T, H, w.setdefault("fp8", {}), score_scale_log2=1.0)
             return None
         if use_flash:
-            ops.flash_attn(w["qkv"], w["ao"], w["lse"], B, T, H, causal)
+            ops.flash_attn(w["qkv"], w["ao"], w["lse"], B, T, H, causal, score_scale_log2=1.0)
             if mean_acc is not None:
                 acc, off, Pn, scale = mean_acc
-                ops.flash_attn_mean(w["qkv"], w["lse"], T, H, off, Pn, scale, acc)
+                ops.flash_attn_mean(w["qkv"], w["lse"], T, H, off, Pn, scale, acc, score_scale_log2=1.0)
             return None
         self.ws_unfused(w, B, T)
         qkv, S, P, VT = w["qkv"], w["S"], w["P"], w["VT"]
@@ -142,7 +159,7 @@ class Tower:
                 z = lambda n, dt: torch.zeros(B * T, n, dtype=dt, device=self.device)     # noqa: E731
                 k = w["keep"] = dict(ln1=z(D, self.dtype), ln2=z(D, self.dtype), x1=z(D, torch.float32), pre=z(blk.fc1.N, self.dtype))
             ops.layernorm(x2, blk.ln1.w, blk.ln1.b, k["ln1"], blk.ln1.eps)
-            ops.linear(k["ln1"], blk.qkv.w, w["qkv"], bias=blk.qkv.b)
+            ops.linear(k["ln1"], blk.qkv.w, w["qkv"], bias=blk.qkv.b, gamma=self.query_scale(need_probs))
             P = self.attention(w, B, T, causal=causal, need_probs=need_probs, mean_acc=mean_acc)
             ops.linear(w["ao"], blk.proj.w, k["x1"], bias=blk.proj.b, gamma=blk.ls1, residual=x2)      # x1 = x + attn
             ops.layernorm(k["x1"], blk.ln2.w, blk.ln2.b, k["ln2"], blk.ln2.eps)
@@ -152,7 +169,7 @@ class Tower:
             keep.update(ln1=k["ln1"], qkv=w["qkv"], ao=w["ao"], x1=k["x1"], ln2=k["ln2"], pre=k["pre"])
             return P
         ops.layernorm(x2, blk.ln1.w, blk.ln1.b, w["xn"], blk.ln1.eps)
-        ops.linear(w["xn"], blk.qkv.w, w["qkv"], bias=blk.qkv.b)
+        ops.linear(w["xn"], blk.qkv.w, w["qkv"], bias=blk.qkv.b, gamma=self.query_scale(need_probs))
         P = self.attention(w, B, T, causal=causal, need_probs=need_probs, mean_acc=mean_acc)
         ops.linear(w["ao"], blk.proj.w, x2, bias=blk.proj.b, gamma=blk.ls1, residual=x2)
         ops.layernorm(x2, blk.ln2.w, blk.ln2.b, w["xn"], blk.ln2.eps)
@@ -251,22 +268,41 @@ class DinoVisionTransformer:
         self.pos0, self.pos_patch = pos[0].contiguous(), pos[1:].contiguous()
         self.regs = sd["register_tokens"].reshape(-1, D).float().to(self.device).contiguous() if cfg.num_regs else None
         self.norm = Norm(sd, "norm", self.device, 1e-6)
-        self._cols: Dict[int, torch.Tensor] = {}
+        self._cols: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def _pos_for(self, gh: int, gw: int) -> torch.Tensor:
+        """interpolate_pos_encoding (vision_transformer.py:188-221) for the patch part: the table as loaded
+        for a square grid of the constructor's size, otherwise resized bicubically with the reference's
+        scale factors (g + 0.1) / M.  Input independent, so prepared once per grid."""
+        M = self.cfg.grid
+        if gh == M and gw == M:
+            return self.pos_patch
+        key = (gh, gw)
+        if key not in self._pos_cache:
+            t = self.pos_patch.reshape(1, M, M, -1).permute(0, 3, 1, 2)
+            r = F.interpolate(t, mode="bicubic", antialias=False, scale_factor=(float(gh + 0.1) / M, float(gw + 0.1) / M))
+            assert tuple(r.shape[-2:]) == (gh, gw)
+            self._pos_cache[key] = r.permute(0, 2, 3, 1).reshape(gh * gw, -1).contiguous()
+        return self._pos_cache[key]
 
     def _tokens(self, x: torch.Tensor, mean=None, std=None) -> torch.Tensor:
-        """prepare_tokens_with_masks (vision_transformer.py:223-243) for inputs of the constructor size."""
+        """prepare_tokens_with_masks (vision_transformer.py:223-243); inputs of another size than the
+        constructor's (multiples of the patch size) get the resized positional table."""
         B, C, H, W = x.shape
         cfg = self.cfg
-        assert C == 3 and H == cfg.img_size and W == cfg.img_size, "input must match the constructor image size"
-        Pn, D, R = cfg.grid * cfg.grid, cfg.embed_dim, cfg.num_regs
+        p = cfg.patch_size
+        assert C == 3 and H % p == 0 and W % p == 0 and H >= p and W >= p, "input sides must be multiples of the patch size"
+        gh, gw = H // p, W // p
+        Pn, D, R = gh * gw, cfg.embed_dim, cfg.num_regs
         T = 1 + R + Pn
-        cols = self._cols.get(B)
+        cols = self._cols.get((B, Pn))
         if cols is None:
-            cols = self._cols[B] = torch.zeros(B * Pn, self.pe.Kp, dtype=self.dtype, device=self.device)
+            cols = self._cols[(B, Pn)] = torch.zeros(B * Pn, self.pe.Kp, dtype=self.dtype, device=self.device)
         ops.im2col(x.contiguous().float(), cfg.patch_size, cols, mean=mean, std=std)
         X = torch.empty(B, T, D, dtype=torch.float32, device=self.device)
         ops.gemm(cols, self.pe.w, X, Pn, D, self.pe.Kp, lda=self.pe.Kp, ldb=self.pe.Kp, ldc=D, c_off=(1 + R) * D, nb0=B,
-                 sA=(Pn * self.pe.Kp, 0), sC=(T * D, 0), bias=self.pe.b, residual=self.pos_patch, ldr=D)
+                 sA=(Pn * self.pe.Kp, 0), sC=(T * D, 0), bias=self.pe.b, residual=self._pos_for(gh, gw), ldr=D)
         ops.write_prefix_tokens(X, self.cls, self.pos0, self.regs)
         return X
 
@@ -279,7 +315,7 @@ class DinoVisionTransformer:
             ma = None
             if mean_attn is not None and i >= L - mean_attn[1]:
                 n = min(mean_attn[1], L)
-                ma = (mean_attn[0], 1 + self.cfg.num_regs, self.cfg.grid ** 2, 1.0 / (n * self.cfg.num_heads))
+                ma = (mean_attn[0], 1 + self.cfg.num_regs, X.shape[1] - 1 - self.cfg.num_regs, 1.0 / (n * self.cfg.num_heads))
             self.tower.block_forward(X, blk, mean_acc=ma)
         return X
 

@@ -217,18 +217,24 @@ def cast(src: torch.Tensor, dst: torch.Tensor):
     hip.check(hip.lib().marship_cast(ptr(src), ptr(dst), src.numel(), dt(src), dt(dst), stream()), "marship_cast")
 
 
-def flash_attn(qkv: torch.Tensor, O: torch.Tensor, lse: Optional[torch.Tensor], B: int, T: int, H: int, causal: bool):
+# What raw queries lack for the softmax to be 2^(scale * q.k): log2(e) / sqrt(64).  Callers whose qkv product has
+# already scaled the queries by it (one rounding instead of two) pass 1.0.
+RAW_QUERY_SCALE_LOG2 = 0.125 * 1.4426950408889634
+
+
+def flash_attn(qkv: torch.Tensor, O: torch.Tensor, lse: Optional[torch.Tensor], B: int, T: int, H: int, causal: bool,
+               score_scale_log2: float = RAW_QUERY_SCALE_LOG2):
     _dev(qkv, O, lse)
     D = H * 64
     _req(qkv.dtype == torch.bfloat16 and O.dtype == torch.bfloat16, "flash_attn: bf16 only")
     _req(B * T * 3 * D <= _avail(qkv) and B * T * D <= _avail(O), "flash_attn: overrun")
     if lse is not None:
         _req(lse.dtype == torch.float32 and B * H * T <= _avail(lse), "flash_attn: lse overrun")
-    hip.check(hip.lib().marship_flash_attn(ptr(qkv), ptr(O), ptr(lse), B, T, H, 1 if causal else 0, stream()),
+    hip.check(hip.lib().marship_flash_attn(ptr(qkv), ptr(O), ptr(lse), B, T, H, 1 if causal else 0, float(score_scale_log2), stream()),
               "marship_flash_attn")
 
 
-def flash_attn_fp8(qkv: torch.Tensor, O: torch.Tensor, B: int, T: int, H: int, ws: dict):
+def flash_attn_fp8(qkv: torch.Tensor, O: torch.Tensor, B: int, T: int, H: int, ws: dict, score_scale_log2: float = RAW_QUERY_SCALE_LOG2):
     """Attention with fp8 (e4m3) operands on packed bf16 qkv.  ``ws`` keeps the quantised operands between calls."""
     _dev(qkv, O)
     D = H * 64
@@ -241,16 +247,16 @@ def flash_attn_fp8(qkv: torch.Tensor, O: torch.Tensor, B: int, T: int, H: int, w
         ws.update(key=key, q8=torch.zeros(n, dtype=torch.uint8, device=qkv.device), k8=torch.zeros(n, dtype=torch.uint8, device=qkv.device),
                   vt8=torch.zeros(n, dtype=torch.uint8, device=qkv.device), scales=torch.zeros(B * H * 6, dtype=torch.float32, device=qkv.device))
     hip.check(hip.lib().marship_flash_attn_fp8(ptr(qkv), ptr(O), B, T, H, ptr(ws["q8"]), ptr(ws["k8"]), ptr(ws["vt8"]), ptr(ws["scales"]),
-                                               Tp, stream()), "marship_flash_attn_fp8")
+                                               Tp, float(score_scale_log2), stream()), "marship_flash_attn_fp8")
 
 
 def flash_attn_mean(qkv: torch.Tensor, lse: torch.Tensor, T: int, H: int, off: int, Pn: int, scale: float,
-                    acc: torch.Tensor):
+                    acc: torch.Tensor, score_scale_log2: float = RAW_QUERY_SCALE_LOG2):
     _dev(qkv, lse, acc)
     _req(qkv.dtype == torch.bfloat16 and T * 3 * H * 64 <= _avail(qkv) and H * T <= _avail(lse), "flash_attn_mean: overrun")
     _req(acc.dtype == torch.float32 and acc.dim() == 2 and acc.stride(1) == 1 and acc.shape[0] >= Pn and acc.shape[1] >= Pn,
          "flash_attn_mean: bad accumulator")
-    hip.check(hip.lib().marship_flash_attn_mean(ptr(qkv), ptr(lse), T, H, off, Pn, scale, ptr(acc), acc.stride(0), stream()),
+    hip.check(hip.lib().marship_flash_attn_mean(ptr(qkv), ptr(lse), T, H, off, Pn, scale, ptr(acc), acc.stride(0), float(score_scale_log2), stream()),
               "marship_flash_attn_mean")
 
 

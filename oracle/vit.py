@@ -42,13 +42,31 @@ def _mha(x, w_in, b_in, w_out, b_out, heads: int, causal: bool = False):
 # ----------------------------------------------------------------------------
 # DINOv2
 # ----------------------------------------------------------------------------
+def dino_pos_embed(sd: SD, gh: int, gw: int, offset: float = 0.1, antialias: bool = False) -> torch.Tensor:
+    """interpolate_pos_encoding, /root/reference/dinov2/models/vision_transformer.py:188-221: the table as
+    it is for a square input of the constructor's size (:192-193), otherwise the patch part resized
+    bicubically with the scale factors (g + 0.1) / M the reference passes (:204-209; ``interpolate_offset``
+    defaults to 0.1, ``interpolate_antialias`` to False, :68-69)."""
+    pos = sd["pos_embed"].float()
+    N = pos.shape[1] - 1
+    if gh * gw == N and gh == gw:
+        return pos
+    M = int(N ** 0.5)
+    assert M * M == N
+    dim = pos.shape[-1]
+    kw = dict(scale_factor=(float(gh + offset) / M, float(gw + offset) / M)) if offset else dict(size=(gh, gw))
+    patch = F.interpolate(pos[:, 1:].reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic", antialias=antialias, **kw)
+    assert tuple(patch.shape[-2:]) == (gh, gw)
+    return torch.cat([pos[:, :1], patch.permute(0, 2, 3, 1).reshape(1, -1, dim)], dim=1)
+
+
 def dino_tokens(sd: SD, x: torch.Tensor, patch: int, num_regs: int) -> torch.Tensor:
-    """/root/reference/dinov2/models/vision_transformer.py:223-243 with the
-    positional table used as-is (input size equals the constructor size, :192-193)."""
+    """/root/reference/dinov2/models/vision_transformer.py:223-243."""
     B = x.shape[0]
     t = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=patch)
+    gh, gw = t.shape[-2:]
     t = t.flatten(2).transpose(1, 2)
-    t = torch.cat([sd["cls_token"].expand(B, -1, -1), t], dim=1) + sd["pos_embed"]
+    t = torch.cat([sd["cls_token"].expand(B, -1, -1), t], dim=1) + dino_pos_embed(sd, gh, gw)
     if num_regs:
         t = torch.cat([t[:, :1], sd["register_tokens"].expand(B, -1, -1), t[:, 1:]], dim=1)
     return t

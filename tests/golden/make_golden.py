@@ -97,6 +97,13 @@ def golden_dino(out):
         out[f"dino_{arch}_x_prenorm"] = ref_x.numpy()
         out[f"dino_{arch}_mean_attn"] = ref_mean.numpy()
         out[f"dino_{arch}_attn_last"] = ref_attn[-1].numpy()
+        if arch == "vit_tiny2":
+            # an input of another size than the constructor's: interpolate_pos_encoding (:188-221), non-square
+            xi = synth.randn(7, "dino_in_interp", (1, 3, 98, 84), 1.0)
+            with torch.no_grad():
+                ref_i = model.forward_features(xi)["x_prenorm"]
+            check("x_prenorm, 98 x 84 input", ref_i, ovit.dino_forward(sd, xi, **kw))
+            out["dino_vit_tiny2_interp_x_prenorm"] = ref_i.numpy()
     # SwiGLU variant (vit_giant2 family) at toy width
     cfg = synth.DinoCfg(embed_dim=128, depth=2, num_heads=2, img_size=70, ffn="swiglu")
     sd = synth.dinov2_state_dict(cfg, seed=2)

@@ -267,29 +267,42 @@ def test_swiglu_cast_l2norm(pkg, cuda):
 
 
 # ------------------------------------------------------------------ fused attention
+@pytest.mark.parametrize("scaled_queries", [True, False])
 @pytest.mark.parametrize("B,T,H,causal", [(1, 64, 1, False), (2, 70, 2, False), (1, 577, 3, False), (3, 77, 2, True), (1, 1374, 2, False)])
-def test_flash_attention_matches_reference(pkg, cuda, B, T, H, causal):
+def test_flash_attention_matches_reference(pkg, cuda, B, T, H, causal, scaled_queries):
+    """``scaled_queries``: the stored queries already carry log2(e)/8 (as the towers' qkv epilogue leaves them) and
+    the kernel is told so; otherwise it scales its query fragments itself, which rounds them to bf16 a second time."""
     D = H * 64
-    qkv = (_rand((B * T, 3 * D), 5, cuda) * 1.5).to(torch.bfloat16)
+    c2 = pkg.ops.RAW_QUERY_SCALE_LOG2
+    x = _rand((B * T, 3 * D), 5, cuda) * 1.5
+    if scaled_queries:
+        x[:, :D] *= c2
+    qkv = x.to(torch.bfloat16)
     O = torch.full((B * T, D), float("nan"), device=cuda, dtype=torch.bfloat16)
     lse = torch.zeros(B * H, T, device=cuda)
-    pkg.ops.flash_attn(qkv, O, lse, B, T, H, causal)
+    scale_arg = 1.0 if scaled_queries else c2
+    pkg.ops.flash_attn(qkv, O, lse, B, T, H, causal, score_scale_log2=scale_arg)
     q = qkv.float().view(B, T, 3, H, 64)
-    s = torch.einsum("bthd,bshd->bhts", q[:, :, 0], q[:, :, 1]) * 0.125
+    # natural-log logits: q.k/8 for raw queries, q'.k ln 2 for scaled ones
+    s = torch.einsum("bthd,bshd->bhts", q[:, :, 0], q[:, :, 1]) * (0.6931471805599453 if scaled_queries else 0.125)
     if causal:
         s = s + torch.full((T, T), float("-inf"), device=cuda).triu_(1)
     ref = torch.einsum("bhts,bshd->bthd", s.softmax(-1), q[:, :, 2]).reshape(B * T, D)
     assert float((O.float() - ref).abs().max()) < 3e-2
     # the row sum is accumulated from the bf16-rounded probabilities (the same values the PV product
-    # uses), so the LSE carries their rounding: 2^-9 relative per term, a few 1e-3 in the worst row
-    assert float((lse.view(B, H, T) - torch.logsumexp(s, -1)).abs().max()) < 4e-3
+    # uses), so the LSE carries their rounding: 2^-9 relative per term, a few 1e-3 in the worst row; the
+    # second rounding of kernel-scaled queries moves every score by up to 2^-9 of its terms on top of that
+    assert float((lse.view(B, H, T) - torch.logsumexp(s, -1)).abs().max()) < (4e-3 if scaled_queries else 1.2e-2)
     if not causal:
         off, Pn = 1, T - 1
         ld = (Pn + 63) // 64 * 64
         acc = torch.zeros(Pn, ld, device=cuda)
-        pkg.ops.flash_attn_mean(qkv, lse, T, H, off, Pn, 1.0 / H, acc)
+        pkg.ops.flash_attn_mean(qkv, lse, T, H, off, Pn, 1.0 / H, acc, score_scale_log2=scale_arg)
         want = s[0].softmax(-1)[:, off:, off:].mean(0)
-        assert float((acc[:, :Pn] - want).abs().max()) < 2e-3
+        assert float((acc[:, :Pn] - want).abs().max()) < (2e-3 if scaled_queries else 4e-3)
+        # both kernels form the same scores, so the mean map's rows sum to what the full rows leave for the patch block
+        rows = acc[:, :Pn].sum(1)
+        assert float((rows - s[0].softmax(-1)[:, off:, off:].sum(-1).mean(0)).abs().max()) < 5e-3
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 70, 2), (2, 577, 3), (1, 33, 2), (1, 1374, 1)])
@@ -344,6 +357,39 @@ def test_flash_attention_spiked_scores(pkg, cuda):
     s = (q[:, 0:64] @ q[:, 64:128].t()) * 0.125
     ref = s.softmax(-1) @ q[:, 128:192]
     assert float((O.float() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("case", ["moderate_spike", "late_huge_spike", "large_first_tile", "very_negative_rows", "two_regimes_in_one_wave"])
+def test_flash_attention_score_ranges(pkg, cuda, case):
+    """The kernel works full key tiles after the first on an absolute exp2 scale when the first tile's row maxima
+    are moderate, and falls back to the running maximum when a score leaves the head room: every regime, and the
+    switch between them in the middle of a sequence, against the f32 softmax (output and log-sum-exp)."""
+    T, H = 330, 1                                   # six key tiles: one classic, four full, one ragged
+    qkv = _rand((T, 192), 21, cuda) * 0.5
+    unit = qkv[7, 0:64] / qkv[7, 0:64].norm()
+    if case == "moderate_spike":                    # +40 nats on one key of a later tile: stays on the absolute scale
+        qkv[200, 64:128] = unit * (8 * 40.0 / float(qkv[7, 0:64].norm()))
+    elif case == "late_huge_spike":                 # +120 nats: beyond the head room, classic from that tile on
+        qkv[200, 64:128] = unit * (8 * 120.0 / float(qkv[7, 0:64].norm()))
+    elif case == "large_first_tile":                # a first-tile maximum of +60 nats: never leaves the classic path
+        qkv[5, 64:128] = unit * (8 * 60.0 / float(qkv[7, 0:64].norm()))
+    elif case == "very_negative_rows":              # every score of the queries far below zero
+        qkv[:, 64:128] = 0.05 * qkv[:, 64:128] - 30.0 * unit
+        qkv[:, 0:64] = 0.05 * qkv[:, 0:64] + 30.0 * unit     # q.k/8 about -112 for all pairs
+    else:                                           # query 40 (second block of the first wave) alone has a late huge spike
+        u2 = qkv[40, 0:64] / qkv[40, 0:64].norm()
+        qkv[250, 64:128] = u2 * (8 * 150.0 / float(qkv[40, 0:64].norm()))
+    qkv = qkv.to(torch.bfloat16)
+    O = torch.zeros(T, 64, device=cuda, dtype=torch.bfloat16)
+    lse = torch.zeros(H, T, device=cuda)
+    pkg.ops.flash_attn(qkv, O, lse, 1, T, H, False)
+    q = qkv.float()
+    s = (q[:, 0:64] @ q[:, 64:128].t()) * 0.125
+    ref = s.softmax(-1) @ q[:, 128:192]
+    assert bool(torch.isfinite(O.float()).all())
+    assert float((O.float() - ref).abs().max()) < 3e-2
+    want = torch.logsumexp(s, -1)
+    assert float(((lse[0] - want).abs() / want.abs().clamp_min(1.0)).max()) < 1.2e-2      # raw queries: scaled in the kernel
 
 
 # ------------------------------------------------------------------ alignment / refinement

@@ -40,6 +40,27 @@ def test_dinov2_fp32_matches_reference_vectors(pkg, cuda, arch, img):
     assert maxdiff(acc[:, :P], G[f"dino_{arch}_mean_attn"]) < TOL
 
 
+def test_dinov2_input_of_another_size_than_the_constructor(pkg, cuda):
+    """interpolate_pos_encoding (vision_transformer.py:188-221): a 98 x 84 input to a tower built for 70 x 70,
+    against the reference module's output, plus the attention-mean side output on the non-square grid."""
+    synth = pkg.synth
+    cfg = synth.dino_cfg("vit_tiny2", img_size=70)
+    sd = synth.dinov2_state_dict(cfg, seed=1)
+    m = _models(pkg).DinoVisionTransformer(cfg, sd, device=cuda, dtype=torch.float32)
+    x = synth.randn(7, "dino_in_interp", (1, 3, 98, 84), 1.0).to(cuda)
+    out = m.forward_features(x)
+    assert out["x_prenorm"].shape == (1, 1 + 4 + 7 * 6, cfg.embed_dim)
+    assert maxdiff(out["x_prenorm"], G["dino_vit_tiny2_interp_x_prenorm"]) < TOL
+    P = 42
+    acc = torch.zeros(P, 64, device=cuda)
+    m.forward_tokens(x, mean_attn=(acc, 24))
+    _, attn = ovit.dino_forward(sd, x.cpu(), want_attn=True, depth=cfg.depth, heads=cfg.num_heads, patch=14, num_regs=4, ffn="mlp")
+    assert maxdiff(acc[:, :P], opipe.mean_attention(attn, cfg.depth, 4)) < TOL
+    # the constructor's own size still takes the table as loaded
+    x0 = synth.randn(7, "dino_in_vit_tiny2", (2, 3, 70, 70), 1.0).to(cuda)
+    assert maxdiff(m.forward_features(x0)["x_prenorm"], G["dino_vit_tiny2_x_prenorm"]) < TOL
+
+
 def test_dinov2_swiglu_fp32(pkg, cuda):
     synth = pkg.synth
     cfg = synth.DinoCfg(embed_dim=128, depth=2, num_heads=2, img_size=70, ffn="swiglu")

@@ -34,6 +34,14 @@ def test_dinov2_forward_and_attention():
         close(opipe.mean_attention(attn, cfg.depth, cfg.num_regs), G[f"dino_{arch}_mean_attn"])
 
 
+def test_dinov2_interpolated_positional_table():
+    cfg = synth.dino_cfg("vit_tiny2", img_size=70)
+    sd = synth.dinov2_state_dict(cfg, seed=1)
+    x = synth.randn(7, "dino_in_interp", (1, 3, 98, 84), 1.0)
+    got = ovit.dino_forward(sd, x, depth=cfg.depth, heads=cfg.num_heads, patch=14, num_regs=cfg.num_regs, ffn="mlp")
+    assert float((got - torch.from_numpy(G["dino_vit_tiny2_interp_x_prenorm"])).abs().max()) < 1e-5
+
+
 def test_dinov2_swiglu():
     cfg = synth.DinoCfg(embed_dim=128, depth=2, num_heads=2, img_size=70, ffn="swiglu")
     sd = synth.dinov2_state_dict(cfg, seed=2)

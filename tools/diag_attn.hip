@@ -25,10 +25,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&st, nst * 8)); CK(hipMemset(st, 0, nst * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(mars_attn_stamps), &st, sizeof(st)));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 10; ++i) marship_flash_attn(qkv, O, lse, B, T, H, 0, nullptr);
+    for (int i = 0; i < 10; ++i) marship_flash_attn(qkv, O, lse, B, T, H, 0, 1.0f, nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    marship_flash_attn(qkv, O, lse, B, T, H, 0, nullptr);
+    marship_flash_attn(qkv, O, lse, B, T, H, 0, 1.0f, nullptr);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
