@@ -44,6 +44,23 @@ typedef struct MarsGemm {
     int32_t act;                     /* 0 none, 1 GELU(erf), 2 QuickGELU, 3 ReLU */
     int32_t in_dtype;                /* A and B: 0 f32, 1 bf16 */
     int32_t out_dtype;               /* C: 0 f32, 1 bf16 */
+    /* A LayerNorm between two products, folded into both (all NULL: plain product; bf16 products, N a multiple
+     * of 64, 16-byte aligned rows, one batch).  The f32 stream the LayerNorm reads is kept as two bf16 planes,
+     * ln_copy = bf16(x) and ln_lo = bf16(x - ln_copy) (x = ln_copy + ln_lo to 16 mantissa bits), row stride
+     * ldcopy; marship_row_stats makes them from f32 rows.  A product that adds to the stream sets ln_copy and
+     * ln_lo: its residual is read from the planes (residual must be NULL), and
+     *   with ln_part: the result goes back into the planes (C is not written) and ln_part receives, per row and
+     *     run of 64 columns, the sum and the sum of squares of the result (marship_ln_finish -> mean, rstd);
+     *   without ln_part: the result goes to C as f32 (the last product of a run). */
+    void* ln_copy;
+    int64_t ldcopy;
+    float* ln_part;                  /* f32 [M, N/64, 2] */
+    /* The product that would have read the normalised rows takes ln_copy as A, weights with the LayerNorm scale
+     * multiplied into their columns, and
+     * out = gamma*act(rstd[m]*(A.B^T - mean[m]*ln_colsum[n]) + bias[n])   (alpha must be 1, no residual): */
+    const float* ln_stat;            /* f32 [M, 2]: mean and 1/sqrt(var + eps) of row m of the stream */
+    const float* ln_colsum;          /* f32 [N]: sum over k of B[n, k] as stored (bf16 values, f32 sum) */
+    void* ln_lo;                     /* bf16 [M, N], row stride ldcopy: see ln_copy */
 } MarsGemm;
 /* Every nn.Linear / conv-as-GEMM / similarity / refinement product on the path:
  * dinov2/layers/attention.py:51,61; mlp.py:35-41; patch_embed.py:76; clip/model.py:283-300,361;
@@ -73,6 +90,14 @@ int marship_gemm_split_rows(const MarsGemm* g);
  * eps 1e-5, computed in f32).  x f32 [rows, D] with row stride x_stride; y out_dtype. */
 int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
                       int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream);
+/* The same LayerNorm (clip/model.py:265-271, alpha_clip/model.py:254-258) folded into the products on either
+ * side of it, see MarsGemm.ln_*: marship_ln_finish turns the row sums a stream product left in ln_part
+ * ([rows, nparts, 2], nparts = N/64) into stat [rows, 2] = mean, 1/sqrt(var + eps) (var = E[x^2] - mean^2 in
+ * f32); marship_row_stats computes the same statistics and the two bf16 planes straight from f32 rows, for the
+ * first LayerNorm of a chain (copy = bf16(x), lo = bf16(x - copy), both [rows, D] with row stride ldcopy). */
+int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, void* stream);
+int marship_row_stats(const float* x, int64_t x_stride, int rows, int D, float eps, void* copy, void* lo,
+                      int64_t ldcopy, float* stat, void* stream);
 /* Patch extraction for the strided conv patch embeddings (patch_embed.py:76; clip/model.py:361;
  * alpha_clip/model.py:359-361) with the input normalisation (x*prescale - mean[c])/std[c] fused
  * (backbone_loader.py:74-78,178-179,185).  img [B,C,H,W] (f32, or u8 when in_u8), out

@@ -263,6 +263,26 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     const int ntm = (g->M + BM - 1) / BM, ntn = (g->N + BN - 1) / BN;
     dim3 grid(ntm * ntn, g->nb0 * g->nb1), block(THREADS);
     hipStream_t s = (hipStream_t)stream;
+    const bool ln_out = g->ln_part || g->ln_lo, ln_in = g->ln_stat || g->ln_colsum;
+    if (ln_out || ln_in) {
+        // the folded LayerNorm forms exist in the register epilogues of the ring kernels only: every wave
+        // tile must take them, so the conditions of those epilogues are requirements here
+        MARS_CHECK(!(ln_out && ln_in), "gemm: a product either adds to the stream or reads it");
+        MARS_CHECK(g->in_dtype == 1 && g->nb0 * g->nb1 == 1 && g->N % 64 == 0, "gemm: folded LayerNorm needs one bf16 product with N a multiple of 64");
+        const int v0 = g_gemm_variant.load(std::memory_order_relaxed);
+        MARS_CHECK(v0 == 3 || v0 == 4 || v0 == 5 || v0 >= 8, "gemm: folded LayerNorm needs one of the ring kernels with at most two waves per SIMD (variant %d set)", v0);
+        MARS_CHECK(((uintptr_t)g->C % 16) == 0 && g->ldc % (g->out_dtype == 1 ? 8 : 4) == 0, "gemm: folded LayerNorm needs 16-byte aligned output rows");
+        if (ln_out) {
+            MARS_CHECK(g->ln_copy && g->ln_lo && g->out_dtype == 0 && g->act == 0 && !g->residual,
+                       "gemm: a product that adds to the stream is f32 = planes + gamma*(A.B^T + bias): ln_copy and ln_lo set, no residual pointer");
+            MARS_CHECK(((uintptr_t)g->ln_copy % 16) == 0 && ((uintptr_t)g->ln_lo % 16) == 0 && g->ldcopy % 8 == 0 && g->ldcopy >= g->N &&
+                       ((uintptr_t)g->ln_part % 8) == 0, "gemm: ln_copy / ln_lo / ln_part alignment");
+        } else {
+            MARS_CHECK(g->ln_stat && g->ln_colsum && g->out_dtype == 1 && (g->act == 0 || g->act == 2) && !g->residual && g->alpha == 1.0f,
+                       "gemm: the product that reads the stream is bf16 = gamma*act(...), act none or QuickGELU, alpha 1, no residual, ln_stat and ln_colsum both set");
+            MARS_CHECK(((uintptr_t)g->ln_stat % 8) == 0, "gemm: ln_stat alignment");
+        }
+    }
     if (g_gemm_variant.load(std::memory_order_relaxed) != 0) {
         const int v = pick_variant(g);
         const int rows = split_rows(g, v);
@@ -274,6 +294,10 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
             tail.A = (const char*)g->A + (int64_t)rows * g->lda * es;
             tail.C = (char*)g->C + (int64_t)rows * g->ldc * (g->out_dtype == 1 ? 2 : 4);
             if (g->residual) tail.residual = g->residual + (int64_t)rows * g->ldr;
+            if (g->ln_copy) tail.ln_copy = (char*)g->ln_copy + (int64_t)rows * g->ldcopy * 2;
+            if (g->ln_lo) tail.ln_lo = (char*)g->ln_lo + (int64_t)rows * g->ldcopy * 2;
+            if (g->ln_part) tail.ln_part = g->ln_part + (int64_t)rows * (g->N / 64) * 2;
+            if (g->ln_stat) tail.ln_stat = g->ln_stat + (int64_t)rows * 2;
             mars_gemm_ring_launch(head, s, v - 4);
             MARS_LAUNCH_CHECK();
             const int vt = pick_variant(&tail);

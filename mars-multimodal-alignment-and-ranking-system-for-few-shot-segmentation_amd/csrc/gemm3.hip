@@ -207,7 +207,9 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     // and the epilogue stores 16 bytes per lane straight from registers.  For 2-byte outputs the B
     // rows are dealt to the fragment pair (2v, 2v+1) so that the pair gives a lane 8 consecutive
     // columns: row index i of fragment n is column 32(n>>1) + 8(i>>2) + 4(n&1) + (i&3).
-    constexpr bool PERM = sizeof(TOUT) == 2;
+    // bf16 products with f32 output deal the rows the same way: 32 consecutive bytes per lane and row, whole
+    // 128-byte lines per four lanes, for the residual loads and the stores of the stream.
+    constexpr bool PERM = sizeof(TOUT) == 2 || sizeof(TIN) == 2;
     auto frag_off = [&](int row) { return row * STEP_B + ((kq ^ gsw((row >> 2) & 3)) << 4); };
     const unsigned a_off = wr * (16 * FM) * STEP_B + frag_off(r16);
     const int brow = PERM ? 8 * (r16 >> 2) + (r16 & 3) : r16;          // fragment 0; fragment 1 is 4 / 16 rows on
@@ -344,34 +346,63 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     const float* Rb = g.residual ? g.residual + (z0 * g.sR0 + z1 * g.sR1) : nullptr;
     const int wrow0 = row0 + wr * (16 * FM), wcol0 = col0 + wc * WN;
     const bool inside = wcol0 + WN <= g.N;       // rows beyond M are masked per lane in the fast variants
-    const bool aligned = (g.ldc % VW == 0) && (((uintptr_t)Cb) % 16 == 0) &&
+    const bool aligned = (g.ldc % (16 / (int)sizeof(TOUT)) == 0) && (((uintptr_t)Cb) % 16 == 0) &&
                          (!Rb || ((g.ldr % 4 == 0) && (((uintptr_t)Rb) % 16 == 0)));
 
-    auto fast = [&](auto mode_tag) {
+    auto fast = [&](auto mode_tag, auto ln_tag) {
         constexpr int MODE = decltype(mode_tag)::value;    // 0 plain, 1 QuickGELU, 2 residual add, 3 erf GELU, 4 ReLU
+        // a LayerNorm folded into the products around it.  The f32 stream is then kept as two bf16 planes, hi =
+        // bf16(x) and lo = bf16(x - hi) (16 mantissa bits between them), so that the plane the next product
+        // takes as its operand is part of the stream and costs no traffic of its own.
+        // 1 = this product adds to the stream: residual from the planes, result back into them, row sums out;
+        // 3 = the same, last of a run: result out as f32;  2 = this product reads hi in place of normalised rows
+        constexpr int LN = decltype(ln_tag)::value;
+        constexpr bool PLANES = LN == 1 || LN == 3;
+        static_assert(LN == 0 || (PLANES && MODE == 2 && sizeof(TOUT) == 4 && VW == 8) || (LN == 2 && MODE <= 1 && sizeof(TOUT) == 2));
         const int lcol = wcol0 + VW * kq;                  // store v of a row starts at lcol + v * VS
-        float bias_[NV][VW], gam_[NV][VW];
+        float bias_[NV][VW], gam_[NV][VW], csum_[LN == 2 ? NV : 1][VW];
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
                 bias_[v][e] = g.bias ? g.bias[lcol + v * VS + e] : 0.f;
                 gam_[v][e] = g.gamma ? g.gamma[lcol + v * VS + e] : 1.f;
+                if constexpr (LN == 2) csum_[v][e] = g.ln_colsum[lcol + v * VS + e];
             }
+        // mean and rstd of the rows this lane holds
+        float mean_[LN == 2 ? FM : 1], rstd_[LN == 2 ? FM : 1];
+        if constexpr (LN == 2) {
+#pragma unroll
+            for (int m = 0; m < FM; ++m) {
+                const int row = min(wrow0 + r16 + 16 * m, g.M - 1);
+                const float2 st = *(const float2*)(g.ln_stat + 2 * (int64_t)row);
+                mean_[m] = st.x;
+                rstd_[m] = st.y;
+            }
+        }
         TOUT* cp = Cb + (int64_t)(wrow0 + r16) * g.ldc + lcol;
         // residual rows are requested PD - 1 fragment rows ahead of their use, in the registers the
         // operand fragments no longer need; a load issued after a store would retire behind it
         constexpr int PD = 3;
-        f32x4 res[PD][NV][VW / 4];
-        const float* rp = (MODE == 2) ? Rb + (int64_t)(wrow0 + r16) * g.ldr + lcol : nullptr;
+        f32x4 res[PLANES ? 1 : PD][NV][VW / 4];
+        bf16x8 rhi[PLANES ? PD : 1][NV], rlo[PLANES ? PD : 1][NV];
+        const float* rp = (MODE == 2 && !PLANES) ? Rb + (int64_t)(wrow0 + r16) * g.ldr + lcol : nullptr;
+        __bf16* hp = PLANES ? (__bf16*)g.ln_copy + (int64_t)(wrow0 + r16) * g.ldcopy + lcol : nullptr;
+        __bf16* lp = PLANES ? (__bf16*)g.ln_lo + (int64_t)(wrow0 + r16) * g.ldcopy + lcol : nullptr;
         const int rows_left = g.M - (wrow0 + r16);         // fragment row m of this lane exists iff 16 m < rows_left
         auto load_res = [&](int m) {
             if (16 * m < rows_left) {
 #pragma unroll
-                for (int v = 0; v < NV; ++v)
+                for (int v = 0; v < NV; ++v) {
+                    if constexpr (PLANES) {
+                        rhi[m % PD][v] = *(const bf16x8*)(hp + (int64_t)m * 16 * g.ldcopy + v * VS);
+                        rlo[m % PD][v] = *(const bf16x8*)(lp + (int64_t)m * 16 * g.ldcopy + v * VS);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < VW / 4; ++q)
-                        res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * VS + 4 * q);
+                        for (int q = 0; q < VW / 4; ++q)
+                            res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * VS + 4 * q);
+                    }
+                }
             }
         };
         if constexpr (MODE == 2) {
@@ -383,24 +414,42 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
             if constexpr (MODE == 2) {
                 if (m + PD - 1 < FM) load_res(m + PD - 1);
             }
+            float rs = 0.f, rss = 0.f;                     // LN == 1: this lane's part of the row sums
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 float x[VW];
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
                     const float a0 = PERM ? acc[m][2 * v + (e >> 2)][e & 3] : acc[m][v][e & 3];
-                    float y = g.alpha * a0 + bias_[v][e];
+                    float y;
+                    if constexpr (LN == 2) y = fmaf(rstd_[m], fmaf(-mean_[m], csum_[v][e], a0), bias_[v][e]);
+                    else y = g.alpha * a0 + bias_[v][e];
                     if constexpr (MODE == 1) y = act_fn3<FAST>(y, 2);
                     if constexpr (MODE == 3) y = act_fn3<FAST>(y, 1);
                     if constexpr (MODE == 4) y = fmaxf(y, 0.f);
                     y *= gam_[v][e];
-                    if constexpr (MODE == 2) y += res[m % PD][v][e >> 2][e & 3];
+                    if constexpr (PLANES) y += (float)rhi[m % PD][v][e] + (float)rlo[m % PD][v][e];
+                    else if constexpr (MODE == 2) y += res[m % PD][v][e >> 2][e & 3];
                     x[e] = y;
+                    if constexpr (LN == 1) {
+                        rs += y;
+                        rss = fmaf(y, y, rss);
+                    }
                 }
                 TOUT* c = cp + (int64_t)m * 16 * g.ldc + v * VS;
                 if (16 * m < rows_left) {
-                    if constexpr (sizeof(TOUT) == 4) {
-                        *(f32x4*)c = (f32x4){x[0], x[1], x[2], x[3]};
+                    if constexpr (LN == 1) {
+                        bf16x8 oh, ol;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            oh[e] = (__bf16)x[e];
+                            ol[e] = (__bf16)(x[e] - (float)oh[e]);
+                        }
+                        *(bf16x8*)(hp + (int64_t)m * 16 * g.ldcopy + v * VS) = oh;
+                        *(bf16x8*)(lp + (int64_t)m * 16 * g.ldcopy + v * VS) = ol;
+                    } else if constexpr (sizeof(TOUT) == 4) {
+#pragma unroll
+                        for (int q = 0; q < VW / 4; ++q) *(f32x4*)(c + 4 * q) = (f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
                     } else {
                         bf16x8 o;
 #pragma unroll
@@ -409,6 +458,15 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                     }
                 }
             }
+            if constexpr (LN == 1) {
+                // the four lanes that share a row (one per group of 16) add their parts; the first writes
+                rs += __shfl_xor(rs, 16);
+                rss += __shfl_xor(rss, 16);
+                rs += __shfl_xor(rs, 32);
+                rss += __shfl_xor(rss, 32);
+                if (kq == 0 && 16 * m < rows_left)
+                    *(float2*)(g.ln_part + ((int64_t)(wrow0 + r16 + 16 * m) * (g.N / WN) + wcol0 / WN) * 2) = make_float2(rs, rss);
+            }
             if (m == FM / 4 - 1) { MARS_STAMP(4) }
             if (m == FM / 2 - 1) { MARS_STAMP(5) }
             if (m == 3 * FM / 4 - 1) { MARS_STAMP(6) }
@@ -416,11 +474,32 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         }
     };
 
-    if (inside && aligned && g.act == 0 && Rb) fast(std::integral_constant<int, 2>{});
-    else if (inside && aligned && g.act == 0 && !Rb) fast(std::integral_constant<int, 0>{});
-    else if (inside && aligned && g.act == 2 && !Rb) fast(std::integral_constant<int, 1>{});
-    else if (inside && aligned && g.act == 1 && !Rb) fast(std::integral_constant<int, 3>{});
-    else if (inside && aligned && g.act == 3 && !Rb) fast(std::integral_constant<int, 4>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // the launcher admits the folded LayerNorm forms only for products every wave tile of which is inside and
+    // aligned (N a multiple of 64), so they never reach the per-element path
+    // (the shapes that keep three or four waves on a SIMD have no registers to spare for them)
+    constexpr bool LN_OUT = FAST && sizeof(TOUT) == 4 && WPE <= 2, LN_IN = FAST && sizeof(TOUT) == 2 && WPE <= 2;
+    const bool planes = LN_OUT && g.ln_lo != nullptr;
+    if (inside && aligned && g.act == 0 && (Rb || planes)) {
+        if constexpr (LN_OUT) {
+            if (planes && g.ln_part) fast(I2{}, I1{});
+            else if (planes) fast(I2{}, std::integral_constant<int, 3>{});
+            else fast(I2{}, I0{});
+        } else fast(I2{}, I0{});
+    } else if (inside && aligned && g.act == 0 && !Rb) {
+        if constexpr (LN_IN) {
+            if (g.ln_stat) fast(I0{}, I2{});
+            else fast(I0{}, I0{});
+        } else fast(I0{}, I0{});
+    } else if (inside && aligned && g.act == 2 && !Rb) {
+        if constexpr (LN_IN) {
+            if (g.ln_stat) fast(I1{}, I2{});
+            else fast(I1{}, I0{});
+        } else fast(I1{}, I0{});
+    } else if (inside && aligned && g.act == 1 && !Rb) fast(std::integral_constant<int, 3>{}, I0{});
+    else if (inside && aligned && g.act == 3 && !Rb) fast(std::integral_constant<int, 4>{}, I0{});
     else {
         constexpr int EP_LD = FN * 16 + 4;
         constexpr int CPL = 16 / (int)sizeof(TOUT), LPR = WN / CPL, RPP = 64 / LPR, NPASS = 32 / RPP;

@@ -89,6 +89,72 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- LayerNorm folded into the products around it
+// mean and rstd of every row from the sums the producing epilogue left per run of 64 columns; sixteen lanes
+// share a row (one 128-byte line of sums per request when a row has sixteen runs) and add in a fixed order
+__global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict__ part, int nparts, int rows, int D, float eps,
+                                                        float* __restrict__ stat) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l16 = threadIdx.x & 15;
+    const bool live = row < rows;
+    const float2* p = (const float2*)(part + (int64_t)(live ? row : 0) * nparts * 2);
+    float s = 0.f, q = 0.f;
+    for (int i = l16; i < nparts; i += 16) {
+        const float2 v = p[i];
+        s += v.x;
+        q += v.y;
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    if (live && l16 == 0) {
+        const float mean = s / (float)D;
+        const float var = fmaxf(q / (float)D - mean * mean, 0.f);
+        *(float2*)(stat + 2 * (int64_t)row) = make_float2(mean, 1.0f / sqrtf(var + eps));
+    }
+}
+
+// the same statistics straight from f32 rows, with the rows as two bf16 planes, copy = bf16(x) and lo =
+// bf16(x - copy) (start of a chain of folded LayerNorms); one wave per row, float4 chunks (i*64 + lane)
+template <int NCH>
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t xs, int rows, int D, float eps,
+                                                        __bf16* __restrict__ copy, __bf16* __restrict__ lo, int64_t ldcopy,
+                                                        float* __restrict__ stat) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4* xr = (const f32x4*)(x + (int64_t)row * xs);
+    __bf16* cr = copy + (int64_t)row * ldcopy;
+    __bf16* lr = lo + (int64_t)row * ldcopy;
+    const int nc = D >> 2;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) {
+            const f32x4 v = xr[c];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            bf16x4 o, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (__bf16)v[e];
+                l[e] = (__bf16)(v[e] - (float)o[e]);
+            }
+            ((bf16x4*)cr)[c] = o;
+            ((bf16x4*)lr)[c] = l;
+        }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        const float mean = s / (float)D;
+        const float var = fmaxf(q / (float)D - mean * mean, 0.f);
+        *(float2*)(stat + 2 * (int64_t)row) = make_float2(mean, 1.0f / sqrtf(var + eps));
+    }
+}
+
 // ---------------------------------------------------------------- im2col
 // one thread per output element of the real (unpadded) K range
 template <typename TOUT, typename TIN>
@@ -277,6 +343,28 @@ extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* 
 #undef MARS_LN
     } else if (out_dtype == 1) hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps);
     else hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, void* stream) {
+    MARS_CHECK(part && stat && rows > 0 && nparts > 0 && D > 0, "ln_finish: bad arguments");
+    MARS_CHECK((uintptr_t)part % 8 == 0 && (uintptr_t)stat % 8 == 0, "ln_finish: pointers must be 8-byte aligned");
+    hipLaunchKernelGGL(ln_finish_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nparts, rows, D, eps, stat);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_row_stats(const float* x, int64_t x_stride, int rows, int D, float eps, void* copy, void* lo,
+                                 int64_t ldcopy, float* stat, void* stream) {
+    MARS_CHECK(x && copy && lo && stat && rows > 0, "row_stats: bad arguments");
+    MARS_CHECK(D > 0 && D <= 2048 && D % 4 == 0 && x_stride % 4 == 0 && ldcopy % 4 == 0 && ldcopy >= D, "row_stats: D=%d / strides not supported", D);
+    MARS_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)copy % 8 == 0 && (uintptr_t)lo % 8 == 0 && (uintptr_t)stat % 8 == 0, "row_stats: alignment");
+    dim3 grid((rows + 3) / 4), block(256);
+    const int nch = (D / 4 + 63) / 64;
+#define MARS_RS(N) hipLaunchKernelGGL((row_stats_kernel<N>), grid, block, 0, (hipStream_t)stream, x, x_stride, rows, D, eps, (__bf16*)copy, (__bf16*)lo, ldcopy, stat);
+    if (nch <= 2) { MARS_RS(2) } else if (nch <= 4) { MARS_RS(4) } else { MARS_RS(8) }
+#undef MARS_RS
     MARS_LAUNCH_CHECK();
     return 0;
 }

@@ -28,6 +28,8 @@ class MarsGemm(Structure):
         ("bias", c_void_p), ("gamma", c_void_p), ("residual", c_void_p),
         ("ldr", c_int64), ("sR0", c_int64), ("sR1", c_int64),
         ("alpha", c_float), ("act", c_int32), ("in_dtype", c_int32), ("out_dtype", c_int32),
+        ("ln_copy", c_void_p), ("ldcopy", c_int64), ("ln_part", c_void_p), ("ln_stat", c_void_p), ("ln_colsum", c_void_p),
+        ("ln_lo", c_void_p),
     ]
 
 
@@ -41,6 +43,8 @@ _SIGNATURES = {
     "marship_set_gemm_split": [_I],
     "marship_gemm_split_rows": [_P],
     "marship_layernorm": [_P, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
+    "marship_ln_finish": [_P, _I, _I, _I, _F, _P, _P],
+    "marship_row_stats": [_P, _L, _I, _I, _F, _P, _P, _L, _P, _P],
     "marship_im2col": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _I, _P],
     "marship_write_prefix_tokens": [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     "marship_transpose": [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _I, _I, _P],

@@ -149,6 +149,7 @@ class Tower:
         """x f32 [B,T,D], updated in place.  ``keep`` (dict) receives the intermediates the CAM backward needs:
         they are written to buffers of their own in this tower's workspace (valid until its next call with
         ``keep`` and the same shape), nothing is copied."""
+        assert not blk.folded, "a block with folded LayerNorms runs in blocks_forward_folded"
         B, T, D = x.shape
         w = self.ws(B, T, blk.hidden_alloc)
         x2 = x.view(B * T, D)
@@ -186,12 +187,47 @@ class Tower:
         return P
 
 
+def _blocks_forward_folded(self, x: torch.Tensor, blocks: List[Block]) -> None:
+    """``block_forward`` over a run of blocks built with ``fold=True``: no LayerNorm pass reads the stream.
+    Inside the run the f32 stream lives in two bf16 planes, hi = bf16(x) and lo = bf16(x - hi).  The products
+    that add to it (attention projection, second MLP layer) read and write the planes and leave the row sums;
+    the products that would have read normalised rows (qkv, first MLP layer) take the hi plane and apply mean
+    and rstd to their accumulators.  x f32 [B,T,D], updated in place (written by the last product of the run)."""
+    B, T, D = x.shape
+    M = B * T
+    w = self.ws(B, T, blocks[0].hidden_alloc)
+    f = w.get("fold")
+    if f is None:
+        f = w["fold"] = dict(hi=torch.zeros(M, D, dtype=self.dtype, device=self.device),
+                             lo=torch.zeros(M, D, dtype=self.dtype, device=self.device),
+                             part=torch.zeros(M, D // 64, 2, dtype=torch.float32, device=self.device),
+                             stat=torch.zeros(M, 2, dtype=torch.float32, device=self.device))
+    hi, lo, part, stat = f["hi"], f["lo"], f["part"], f["stat"]
+    x2 = x.view(M, D)
+    ops.row_stats(x2, blocks[0].ln1.eps, hi, lo, stat)
+    for i, blk in enumerate(blocks):
+        assert blk.folded
+        ops.linear(hi, blk.qkv.w, w["qkv"], bias=blk.qkv.b, gamma=self.query_scale(False), ln_in=(stat, blk.qkv_colsum))
+        self.attention(w, B, T, causal=False, need_probs=False)
+        ops.linear(w["ao"], blk.proj.w, x2, bias=blk.proj.b, gamma=blk.ls1, ln_out=(hi, lo, part))
+        ops.ln_finish(part, M, D, blk.ln2.eps, stat)
+        ops.linear(hi, blk.fc1.w, w["hid"], bias=blk.fc1.b, act=blk.act, ln_in=(stat, blk.fc1_colsum))
+        if i + 1 < len(blocks):
+            ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, ln_out=(hi, lo, part))
+            ops.ln_finish(part, M, D, blocks[i + 1].ln1.eps, stat)
+        else:
+            ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, ln_out=(hi, lo, None))
+
+
+Tower.blocks_forward_folded = _blocks_forward_folded
+
+
 def _first_token_block(self, x: torch.Tensor, blk: Block) -> torch.Tensor:
     """The block's output for token 0 of every sequence, [B, D] f32 (x is left as it is).  A tower whose head
     reads only the class token needs nothing else from its last block: keys and values still come from every
     token, but the query, the attention output, both residual adds and the MLP are formed for one row per
     sequence (same arithmetic per row as ``block_forward``; the attention is the unfused form)."""
-    assert blk.ffn == "mlp"
+    assert blk.ffn == "mlp" and not blk.folded
     B, T, D = x.shape
     H, dtp, dev = self.H, self.dtype, self.device
     w = self.ws(B, T, blk.hidden_alloc)
@@ -225,13 +261,31 @@ def _first_token_block(self, x: torch.Tensor, blk: Block) -> torch.Tensor:
 Tower.block_forward_first_token = _first_token_block
 
 
-def _make_block(sd: SD, names: dict, D: int, device, dtype, eps: float, act: int, ffn: str = "mlp") -> Block:
+def _fold_norm(w: torch.Tensor, b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor):
+    """Linear(LayerNorm(x)) = rstd * (x . (w*ln_w)^T - mean * rowsum(w*ln_w)) + (b + w . ln_b): the weights and
+    bias of the product that takes x itself."""
+    w, ln_w, ln_b = w.float(), ln_w.float(), ln_b.float()
+    return w * ln_w[None, :], b.float() + w @ ln_b
+
+
+def _make_block(sd: SD, names: dict, D: int, device, dtype, eps: float, act: int, ffn: str = "mlp", fold: bool = False) -> Block:
+    """``fold``: the two LayerNorms are folded into the qkv and fc1 products (``Tower.blocks_forward_folded``
+    is then the only way to run the block)."""
     b = Block()
     b.ln1 = Norm(sd, names["ln1"], device, eps)
     b.ln2 = Norm(sd, names["ln2"], device, eps)
-    b.qkv = Lin(sd[names["qkv_w"]], sd[names["qkv_b"]], dtype, device)
+    b.folded = fold
+    if fold:
+        assert ffn == "mlp" and dtype == torch.bfloat16
+        b.qkv = Lin(*_fold_norm(sd[names["qkv_w"]], sd[names["qkv_b"]], sd[names["ln1"] + ".weight"], sd[names["ln1"] + ".bias"]), dtype, device)
+        b.fc1 = Lin(*_fold_norm(sd[names["fc1"] + ".weight"], sd[names["fc1"] + ".bias"], sd[names["ln2"] + ".weight"], sd[names["ln2"] + ".bias"]), dtype, device)
+        # sums of the weights as the matrix pipe sees them (rounded), in f32
+        b.qkv_colsum = b.qkv.w.float().sum(dim=1).contiguous()
+        b.fc1_colsum = b.fc1.w.float().sum(dim=1).contiguous()
+    else:
+        b.qkv = Lin(sd[names["qkv_w"]], sd[names["qkv_b"]], dtype, device)
+        b.fc1 = Lin(sd[names["fc1"] + ".weight"], sd[names["fc1"] + ".bias"], dtype, device)
     b.proj = Lin(sd[names["proj"] + ".weight"], sd[names["proj"] + ".bias"], dtype, device)
-    b.fc1 = Lin(sd[names["fc1"] + ".weight"], sd[names["fc1"] + ".bias"], dtype, device)
     b.fc2 = Lin(sd[names["fc2"] + ".weight"], sd[names["fc2"] + ".bias"], dtype, device)
     b.ls1 = sd[names["ls1"]].float().to(device).contiguous() if names.get("ls1") else None
     b.ls2 = sd[names["ls2"]].float().to(device).contiguous() if names.get("ls2") else None
@@ -579,16 +633,22 @@ class CLIP(_TextTower):
 
 
 class AlphaCLIP(_TextTower):
-    def __init__(self, cfg: ClipCfg, sd: SD, device="cuda", dtype=torch.float32):
+    def __init__(self, cfg: ClipCfg, sd: SD, device="cuda", dtype=torch.float32, fold_ln: Optional[bool] = None):
         device = torch.device(device)
         super().__init__(cfg, sd, device, dtype)
         W, p = cfg.vision_width, cfg.vision_patch_size
         self.vtower = Tower(W, cfg.vision_heads, device, dtype)
+        if fold_ln is None:
+            fold_ln = os.environ.get("MARS_FOLD_LN", "1") != "0"
+        self.fold_ln = bool(fold_ln) and dtype == torch.bfloat16 and W % 64 == 0
         for i in range(cfg.vision_layers):
             pre = f"visual.transformer.resblocks.{i}"
             names = dict(ln1=pre + ".ln_1", ln2=pre + ".ln_2", qkv_w=pre + ".attn.in_proj.weight", qkv_b=pre + ".attn.in_proj.bias",
                          proj=pre + ".attn.out_proj", fc1=pre + ".mlp.c_fc", fc2=pre + ".mlp.c_proj")
-            self.vtower.blocks.append(_make_block(sd, names, W, device, dtype, 1e-5, ACT_QUICKGELU))
+            # every block but the last (whose first-token form normalises single rows) has its LayerNorms
+            # folded into the products around them; MARS_FOLD_LN=0 keeps the stand-alone passes
+            fold = self.fold_ln and i + 1 < cfg.vision_layers
+            self.vtower.blocks.append(_make_block(sd, names, W, device, dtype, 1e-5, ACT_QUICKGELU, fold=fold))
         # RGB and alpha patch embeddings share one GEMM: K = 3*p*p (image) + p*p (alpha)
         w_rgba = torch.cat([sd["visual.conv1.weight"].reshape(W, 3 * p * p), sd["visual.conv1_alpha.weight"].reshape(W, p * p)], dim=1)
         self.conv_rgb = Lin(sd["visual.conv1.weight"].reshape(W, 3 * p * p), None, dtype, device)
@@ -646,8 +706,11 @@ class AlphaCLIP(_TextTower):
         ops.write_prefix_tokens(X, self.class_embedding, self.vpos[0], None)
         X2 = X.view(n * T, D)
         ops.layernorm(X2, self.ln_pre.w, self.ln_pre.b, X2, self.ln_pre.eps)
-        for blk in self.vtower.blocks[:-1]:
-            self.vtower.block_forward(X, blk)
+        if self.fold_ln and len(self.vtower.blocks) > 1:
+            self.vtower.blocks_forward_folded(X, self.vtower.blocks[:-1])
+        else:
+            for blk in self.vtower.blocks[:-1]:
+                self.vtower.block_forward(X, blk)
         if self.first_token_last_block:
             cls_rows = self.vtower.block_forward_first_token(X, self.vtower.blocks[-1])   # only the class token is read below
         else:

@@ -66,9 +66,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: i
          a_off: int = 0, b_off: int = 0, c_off: int = 0, nb0: int = 1, nb1: int = 1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias: Optional[torch.Tensor] = None,
          gamma: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, r_off: int = 0, ldr: int = 0,
-         sR=(0, 0), alpha: float = 1.0, act: int = 0):
-    """C[M,N] (+batches) = epilogue(A[M,K] . B[N,K]^T).  Offsets and strides are in elements."""
-    _dev(A, B, C, bias, gamma, residual)
+         sR=(0, 0), alpha: float = 1.0, act: int = 0, ln_out=None, ln_in=None):
+    """C[M,N] (+batches) = epilogue(A[M,K] . B[N,K]^T).  Offsets and strides are in elements.
+    A LayerNorm folded into the products around it: ``ln_out`` = (hi bf16 [M,N], lo bf16 [M,N], part f32
+    [M,N/64,2] or None) on a product that adds to the stream kept in the two planes (part None: the result goes
+    to C as f32, otherwise back into the planes), ``ln_in`` = (stat f32 [M,2], colsum f32 [N]) on the one that
+    reads the hi plane in place of normalised rows."""
+    _dev(A, B, C, bias, gamma, residual, *(t for t in (ln_out or ()) if t is not None), *(ln_in or ()))
     _req(A.dtype == B.dtype, "A and B must share a dtype")
     _req(M > 0 and N > 0 and K > 0, "empty gemm")
     ea = A.element_size()
@@ -98,6 +102,20 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: i
     g.residual = residual.data_ptr() + r_off * 4 if residual is not None else None
     g.ldr, g.sR0, g.sR1 = ldr, sR[0], sR[1]
     g.alpha, g.act, g.in_dtype, g.out_dtype = alpha, act, dt(A), dt(C)
+    if ln_out is not None:
+        hi, lo, part = ln_out
+        for pl in (hi, lo):
+            _req(pl.dtype == torch.bfloat16 and pl.dim() == 2 and pl.stride(1) == 1 and pl.shape[0] >= M and pl.shape[1] >= N, "ln_out planes must be bf16 [M,N]")
+        _req(hi.stride(0) == lo.stride(0), "ln_out planes must share a row stride")
+        g.ln_copy, g.ln_lo, g.ldcopy = hi.data_ptr(), lo.data_ptr(), hi.stride(0)
+        if part is not None:
+            _req(part.dtype == torch.float32 and part.is_contiguous() and N % 64 == 0 and part.numel() >= M * (N // 64) * 2, "ln_out part must be f32 [M,N/64,2]")
+            g.ln_part = part.data_ptr()
+    if ln_in is not None:
+        stat, colsum = ln_in
+        _req(stat.dtype == torch.float32 and stat.is_contiguous() and stat.numel() >= 2 * M, "ln_in stat must be f32 [M,2]")
+        _req(colsum.dtype == torch.float32 and colsum.is_contiguous() and colsum.numel() >= N, "ln_in colsum must be f32 [N]")
+        g.ln_stat, g.ln_colsum = stat.data_ptr(), colsum.data_ptr()
     if GEMM_PROFILE is not None and dt(A) == GEMM_PROFILE_DTYPE:
         rows = hip.lib().marship_gemm_split_rows(ctypes.byref(g))
         if rows < M:
@@ -105,9 +123,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: i
             old = hip.lib().marship_set_gemm_split(0)
             try:
                 for r0, m in ((0, rows), (rows, M - rows)):
+                    lo = (ln_out[0][r0:], ln_out[1][r0:], None if ln_out[2] is None else ln_out[2].view(-1, N // 64, 2)[r0:]) if ln_out is not None else None
+                    li = (ln_in[0].view(-1, 2)[r0:], ln_in[1]) if ln_in is not None else None
                     gemm(A, B, C, m, N, K, lda=lda, ldb=ldb, ldc=ldc, a_off=a_off + r0 * lda, b_off=b_off,
                          c_off=c_off + r0 * ldc, bias=bias, gamma=gamma, residual=residual, r_off=r_off + r0 * ldr,
-                         ldr=ldr, alpha=alpha, act=act)
+                         ldr=ldr, alpha=alpha, act=act, ln_out=lo, ln_in=li)
             finally:
                 hip.lib().marship_set_gemm_split(old)
             return
@@ -127,7 +147,7 @@ def _avail(t: torch.Tensor) -> int:
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = 0, gamma=None,
-           residual: Optional[torch.Tensor] = None, alpha: float = 1.0):
+           residual: Optional[torch.Tensor] = None, alpha: float = 1.0, ln_out=None, ln_in=None):
     """out[M,N] = epilogue(x[M,K] . w[N,K]^T) for row-major 2-D views (last dim contiguous)."""
     _req(x.dim() == 2 and w.dim() == 2 and out.dim() == 2, "linear expects 2-D tensors")
     _req(x.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1, "last dim must be contiguous")
@@ -138,7 +158,30 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, ac
         _req(residual.dim() == 2 and residual.shape[0] == M and residual.shape[1] == N and residual.stride(1) == 1,
              "residual shape mismatch")
     gemm(x, w, out, M, N, K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, gamma=gamma,
-         residual=residual, ldr=residual.stride(0) if residual is not None else 0, alpha=alpha, act=act)
+         residual=residual, ldr=residual.stride(0) if residual is not None else 0, alpha=alpha, act=act,
+         ln_out=ln_out, ln_in=ln_in)
+
+
+def ln_finish(part: torch.Tensor, rows: int, D: int, eps: float, stat: torch.Tensor):
+    """stat[rows,2] = mean, rstd of the rows whose sums a stream product left in ``part`` [rows, D/64, 2]."""
+    _dev(part, stat)
+    _req(part.dtype == torch.float32 and stat.dtype == torch.float32 and part.is_contiguous() and stat.is_contiguous(), "ln_finish: f32 contiguous")
+    _req(D % 64 == 0 and part.numel() >= rows * (D // 64) * 2 and stat.numel() >= 2 * rows, "ln_finish: sizes")
+    hip.check(hip.lib().marship_ln_finish(ptr(part), D // 64, rows, D, eps, ptr(stat), stream()), "marship_ln_finish")
+
+
+def row_stats(x: torch.Tensor, eps: float, hi: torch.Tensor, lo: torch.Tensor, stat: torch.Tensor):
+    """hi = bf16(x), lo = bf16(x - hi), stat[rows,2] = mean, rstd of the f32 rows of x."""
+    _dev(x, hi, lo, stat)
+    _req(x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "row_stats: x must be f32 rows")
+    rows, D = x.shape
+    for pl in (hi, lo):
+        _req(pl.dtype == torch.bfloat16 and pl.dim() == 2 and pl.stride(1) == 1 and pl.shape[0] >= rows and pl.shape[1] >= D, "row_stats: planes")
+    _req(hi.stride(0) == lo.stride(0), "row_stats: planes must share a row stride")
+    _req(stat.dtype == torch.float32 and stat.is_contiguous() and stat.numel() >= 2 * rows, "row_stats: stat")
+    _req((rows - 1) * x.stride(0) + D <= _avail(x), "row_stats: overrun")
+    hip.check(hip.lib().marship_row_stats(ptr(x), x.stride(0), rows, D, eps, ptr(hi), ptr(lo), hi.stride(0), ptr(stat), stream()),
+              "marship_row_stats")
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float):

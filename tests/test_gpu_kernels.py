@@ -141,6 +141,101 @@ def test_gemm_split_launch(pkg, cuda):
     assert torch.equal(x1[:rows], x2[:rows])
 
 
+@pytest.mark.parametrize("M,D,N2,K2", [(1000, 128, 384, 512), (4616, 1024, 4096, 1024), (36928, 1024, 3072, 4096)])
+def test_gemm_folded_layernorm(pkg, cuda, M, D, N2, K2):
+    """A LayerNorm between two products, folded into both: the product that writes the f32 stream leaves its
+    rounded copy and the row sums, the product that would have read the normalised rows applies mean and rstd
+    to its accumulators.  (The last shape runs the stream product as two launches.)"""
+    ops = pkg.ops
+    eps = 1e-5
+    x0 = (_rand((M, D), 1, cuda) * 0.7 + 0.3)                      # stream before the product, mean != 0
+    h = _rand((M, K2), 2, cuda).to(torch.bfloat16)
+    w2 = (_rand((D, K2), 3, cuda) * 0.05).to(torch.bfloat16)
+    b2 = _rand((D,), 4, cuda)
+    ls = _rand((D,), 5, cuda) * 0.5 + 1.0
+    nan16 = lambda: torch.full((M, D), float("nan"), device=cuda, dtype=torch.bfloat16)        # noqa: E731
+    hi, lo, stat0 = nan16(), nan16(), torch.full((M, 2), float("nan"), device=cuda)
+    # the stream as two bf16 planes, with the statistics of its rows
+    ops.row_stats(x0, eps, hi, lo, stat0)
+    assert torch.equal(hi, x0.to(torch.bfloat16)) and torch.equal(lo, (x0 - hi.float()).to(torch.bfloat16))
+    xr = hi.float() + lo.float()                                   # what the planes hold: x0 to 16 mantissa bits
+    assert float(((xr - x0).abs() - 2.0 ** -16 * x0.abs()).max()) <= 0
+    xd0 = x0.double()
+    assert float((stat0[:, 0].double() - xd0.mean(1)).abs().max()) < 1e-5
+    assert float((stat0[:, 1].double() * torch.sqrt(xd0.var(1, unbiased=False) + eps) - 1).abs().max()) < 1e-4
+    # a product that adds to the stream: same f32 values as the plain product on the reconstructed stream
+    plain = xr.clone()
+    ops.linear(h, w2, plain, bias=b2, gamma=ls, residual=plain)
+    last = torch.full((M, D), float("nan"), device=cuda)
+    ops.linear(h, w2, last, bias=b2, gamma=ls, ln_out=(hi, lo, None))          # last of a run: f32 out
+    assert torch.equal(last, plain)
+    part = torch.full((M, D // 64, 2), float("nan"), device=cuda)
+    stat = torch.full((M, 2), float("nan"), device=cuda)
+    untouched = torch.full((M, D), 7.0, device=cuda)
+    ops.linear(h, w2, untouched, bias=b2, gamma=ls, ln_out=(hi, lo, part))      # inside a run: back into the planes
+    assert bool((untouched == 7.0).all())
+    xb = hi
+    assert torch.equal(hi, plain.to(torch.bfloat16)) and torch.equal(lo, (plain - hi.float()).to(torch.bfloat16))
+    ops.ln_finish(part, M, D, eps, stat)
+    x = plain
+    xd = x.double()
+    assert float((part[:, :, 0].double().sum(1) - xd.sum(1)).abs().max()) < 1e-3 * D ** 0.5
+    mean, var = xd.mean(1), xd.var(1, unbiased=False)
+    assert float((stat[:, 0].double() - mean).abs().max()) < 1e-5
+    assert float((stat[:, 1].double() * torch.sqrt(var + eps) - 1).abs().max()) < 1e-4
+    # consumer: N2 outputs from the normalised rows, QuickGELU or none, with a per-column factor
+    lnw, lnb = _rand((D,), 6, cuda) * 0.2 + 1.0, _rand((D,), 7, cuda) * 0.1
+    w1, b1 = _rand((N2, D), 8, cuda) * 0.05, _rand((N2,), 9, cuda) * 0.1
+    wf, bf = pkg.models._fold_norm(w1, b1, lnw, lnb)
+    wf = wf.to(torch.bfloat16)
+    colsum = wf.float().sum(1).contiguous()
+    gam = _rand((N2,), 10, cuda) * 0.3 + 1.0
+    for act in (0, 2):
+        out = torch.full((M, N2), float("nan"), device=cuda, dtype=torch.bfloat16)
+        ops.linear(xb, wf, out, bias=bf, act=act, gamma=gam, ln_in=(stat, colsum))
+        rows = slice(0, M) if M <= 5000 else torch.cat([torch.arange(0, 700), torch.arange(32700, 33400), torch.arange(M - 300, M)]).to(cuda)
+        # the arithmetic of the kernel, in f64 on the same operands
+        t = xb[rows].double() @ wf.double().t()
+        y = stat[rows, 1:2].double() * (t - stat[rows, 0:1].double() * colsum.double()[None]) + bf.double()[None]
+        if act == 2:
+            y = y * torch.sigmoid(1.702 * y)
+        y = y * gam.double()[None]
+        err = (out[rows].double() - y).abs()
+        assert float((err - 2.0 ** -8 * y.abs()).max()) < 2e-3, float(err.max())
+        # ...and what it stands for: the product of the normalised f32 rows
+        ln = torch.nn.functional.layer_norm(x[rows], (D,), lnw, lnb, eps)
+        z = ln.double() @ w1.double().t() + b1.double()[None]
+        if act == 2:
+            z = z * torch.sigmoid(1.702 * z)
+        z = z * gam.double()[None]
+        stand_alone = torch.zeros(ln.shape[0], N2, device=cuda, dtype=torch.bfloat16)
+        ops.linear(ln.to(torch.bfloat16), w1.to(torch.bfloat16), stand_alone, bias=b1, act=act, gamma=gam)
+        e_fold = float((out[rows].double() - z).abs().max())
+        e_alone = float((stand_alone.double() - z).abs().max())
+        assert e_fold < 1.5 * e_alone + 1e-3, (e_fold, e_alone)
+
+
+def test_gemm_folded_layernorm_is_refused_where_no_kernel_takes_it(pkg, cuda):
+    ops = pkg.ops
+    M, D = 128, 128
+    x = _rand((M, D), 1, cuda)
+    h = _rand((M, 64), 2, cuda).to(torch.bfloat16)
+    w = _rand((D, 64), 3, cuda).to(torch.bfloat16)
+    xb, lo = torch.zeros(M, D, device=cuda, dtype=torch.bfloat16), torch.zeros(M, D, device=cuda, dtype=torch.bfloat16)
+    part, stat, colsum = torch.zeros(M, D // 64, 2, device=cuda), torch.zeros(M, 2, device=cuda), torch.zeros(D, device=cuda)
+    with pytest.raises(RuntimeError):                      # the residual of a stream product comes from the planes
+        ops.linear(h, w, x, residual=x, ln_out=(xb, lo, part))
+    with pytest.raises(RuntimeError):                      # ...and it has no activation
+        ops.linear(h, w, x, act=2, ln_out=(xb, lo, part))
+    with pytest.raises(RuntimeError):                      # erf GELU has no folded form
+        ops.linear(h, w, xb, act=1, ln_in=(stat, colsum))
+    with pytest.raises(RuntimeError):                      # f32 operands have no folded form
+        ops.linear(h.float(), w.float(), xb, ln_in=(stat, colsum))
+    w96 = _rand((96, 64), 3, cuda).to(torch.bfloat16)
+    with pytest.raises((RuntimeError, ValueError)):        # N must be a multiple of 64
+        ops.linear(h, w96, torch.zeros(M, 96, device=cuda, dtype=torch.bfloat16), ln_in=(stat, torch.zeros(96, device=cuda)))
+
+
 def test_gemm_large_m(pkg, cuda):
     """Default launch policy on a tall product (the shape of the AlphaCLIP batch): in-place residual,
     ragged last row tile, both output types."""

@@ -151,6 +151,28 @@ def test_alphaclip_fp32_and_bf16(pkg, cuda):
     assert float(cos.min()) > 0.995
 
 
+def test_alphaclip_folded_layernorms(pkg, cuda):
+    """bf16 tower with its LayerNorms folded into the products around them against the same tower with
+    stand-alone passes: both are one bf16 rounding per operand away from the f32 tower."""
+    synth = pkg.synth
+    cfg = synth.CLIP_ARCHS["tiny/14"]
+    sd = synth.clip_state_dict(cfg, seed=4, alpha=True)
+    R = cfg.image_resolution
+    img1 = synth.randn(7, "aclip_img", (1, 3, R, R), 1.0).to(cuda)
+    alpha = synth.randn(7, "aclip_alpha", (3, 1, R, R), 1.5).to(cuda)
+    ref = torch.from_numpy(G["aclip_visual"]).to(cuda)
+    M = _models(pkg)
+    folded = M.AlphaCLIP(cfg, sd, device=cuda, dtype=torch.bfloat16, fold_ln=True)
+    alone = M.AlphaCLIP(cfg, sd, device=cuda, dtype=torch.bfloat16, fold_ln=False)
+    assert folded.fold_ln and folded.vtower.blocks[0].folded and not folded.vtower.blocks[-1].folded
+    assert not alone.fold_ln and not alone.vtower.blocks[0].folded
+    ff, fa = folded.visual(img1, alpha).clone(), alone.visual(img1, alpha).clone()
+    e_fold, e_alone = maxdiff(ff, ref), maxdiff(fa, ref)
+    assert e_fold < 1.5 * e_alone + 1e-3 * float(ref.abs().max()), (e_fold, e_alone)
+    folded.first_token_last_block = False                      # the whole last block behind the folded run
+    assert maxdiff(folded.visual(img1, alpha), ff) < 0.05 * max(1.0, float(ff.abs().max()))
+
+
 def test_backbone_loader_seam(pkg, cuda):
     BL = importlib.import_module(pkg.__name__ + ".utils.backbone_loader").BackboneLoader
     enc, tr = BL.load_backbone("dinov2", "vit_tiny2", None, "cuda:0", dict(img_size=70, patch_size=14, num_register_tokens=4, seed=1))
