@@ -66,9 +66,26 @@ __device__ __forceinline__ int gsw(int x) { return (4 - x) & 3; }
 
 template <bool FAST>
 __device__ __forceinline__ float act_fn3(float v, int act) {
-    if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 1) {
+        if constexpr (FAST) {
+            // erf by Abramowitz & Stegun 7.1.26 (absolute error below 1.5e-7, far inside a bf16 result) on the
+            // hardware exp2 and reciprocal: a third of the instructions of erff
+            const float z = fabsf(v) * 0.70710678118654752440f;
+            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+            float p = fmaf(1.061405429f, t, -1.453152027f);
+            p = fmaf(p, t, 1.421413741f);
+            p = fmaf(p, t, -0.284496736f);
+            p = fmaf(p, t, 0.254829592f);
+            const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+            const float erf_abs = fmaf(-p * t, e, 1.0f);
+            return 0.5f * v + 0.5f * fabsf(v) * erf_abs;      // v * erf(v / sqrt 2) = |v| * erf(|v| / sqrt 2)
+        }
+        return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    }
     if (act == 2) {
-        if constexpr (FAST) return v * __frcp_rn(1.0f + __expf(-1.702f * v));
+        // v / (1 + 2^(-1.702 log2(e) v)) on the hardware exp2 and reciprocal (1 ulp each; __frcp_rn would be a
+        // correctly rounded division, ten more instructions per output that a bf16 result cannot show)
+        if constexpr (FAST) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));
         else return v / (1.0f + expf(-1.702f * v));
     }
     if (act == 3) return fmaxf(v, 0.f);

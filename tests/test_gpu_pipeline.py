@@ -139,3 +139,28 @@ def test_side_stream_start_gives_the_same_result(pkg, cuda):
     assert torch.equal(out[False][0], out[True][0])
     for k in ("emd", "aclip", "score", "order"):
         assert torch.equal(out[False][1][k], out[True][1][k]), k
+
+
+two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
+
+
+@two_gpus
+def test_operands_of_another_gpu_are_refused(pkg, cuda):
+    """Kernels go to the current device's stream: an operand that lives on another GPU is an error, not a launch."""
+    torch.cuda.set_device(0)
+    a = torch.zeros(64, 64, device="cuda:1")
+    with pytest.raises(ValueError, match="current device"):
+        pkg.ops.linear(a, a, torch.zeros(64, 64, device="cuda:1"))
+    with torch.cuda.device(1):
+        out = torch.full((64, 64), float("nan"), device="cuda:1")
+        pkg.ops.linear(torch.eye(64, device="cuda:1"), torch.eye(64, device="cuda:1"), out)
+        assert torch.equal(out, torch.eye(64, device="cuda:1"))
+
+
+@two_gpus
+def test_episode_on_a_gpu_that_is_not_current(pkg, cuda):
+    """``args.device = cuda:1`` while cuda:0 is current: the builders and ``predict`` select the device themselves."""
+    torch.cuda.set_device(0)
+    rep = run_tiny_episode_parity(pkg, device="cuda:1", seed=3, dtype=torch.float32, tol=TOL)
+    assert rep["order_equal"] and rep["mask_mismatch"] == 0, rep
+    assert torch.cuda.current_device() == 0

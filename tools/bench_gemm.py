@@ -28,6 +28,7 @@ SHAPES = [
     ("clip  qkv   ", 1090, 2304, 768, torch.bfloat16, "bias"),
     ("clip  fc2   ", 1090, 768, 3072, torch.float32, "res"),
     ("clip  fc1   ", 1090, 3072, 768, torch.bfloat16, "gelu"),
+    ("clip  proj  ", 1090, 768, 768, torch.float32, "res"),
     ("pir   f32   ", 1369, 1369, 1408, torch.float32, "f32"),
     ("sim   f32   ", 1369, 1369, 1024, torch.float32, "f32"),
 ]
@@ -48,8 +49,11 @@ def run(shape, variant, a, b, out, bias, res):
     ops.linear(a, b, out, **kw)
 
 
+ONLY = [t for t in os.environ.get("ONLY", "").split(",") if t]
 for shape in SHAPES:
     name, M, N, K, odt, epi = shape
+    if ONLY and not any(name.startswith(t) for t in ONLY):
+        continue
     g = torch.Generator(device="cpu").manual_seed(0)
     idt = torch.float32 if epi == "f32" else torch.bfloat16
     a = (torch.rand(M, K, generator=g) * 2 - 1).to(dev).to(idt)

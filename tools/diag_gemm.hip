@@ -15,13 +15,15 @@
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 36928, N = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 1024;
-    const int shape = argc > 4 ? atoi(argv[4]) : 1;   // 0: 256x256, 1: 256x128, 2: 128x128, 3: 64x128, 4 / 5: 256x256 with pair fills (4 / 5 slots)
+    const int shape = argc > 4 ? atoi(argv[4]) : 1;   // 0: 256x256, 1: 256x128, 2: 128x128, 3: 64x128, 4: 256x256 with pair fills
     const bool out_f32 = argc > 5 ? atoi(argv[5]) != 0 : true;
     const bool resid = argc > 6 ? atoi(argv[6]) != 0 : true;
     
     
     if (argc > 7) mars_ring_group_m = atoi(argv[7]);
-    const int BMt = shape == 2 ? 128 : shape == 3 ? 64 : 256, BN = (shape == 0 || shape >= 4) ? 256 : 128, NW = (shape == 0 || shape >= 4) ? 8 : 4;
+    // 5 / 7: 128x128 with pair fills (eight / four slots), 6: 64x128 with pair fills
+    const int BMt = (shape == 2 || shape == 5 || shape == 7) ? 128 : (shape == 3 || shape == 6) ? 64 : 256;
+    const int BN = (shape == 0 || shape == 4) ? 256 : 128, NW = (shape == 0 || shape == 4) ? 8 : 4;
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
     unsigned x = 12345u;
     for (auto& v : ha) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((x >> 9) & 0x3ffu) + ((x >> 3) & 0x8000u)); }
