@@ -193,7 +193,8 @@ static int pick_variant(const MarsGemm* g) {
         // long products without an activation run faster on the 256 x 256 shape with pair fills (one barrier
         // per 128 bytes of K); an activation epilogue, or a short product whose time is mostly its residual
         // traffic, is better hidden behind the second 256 x 128 workgroup of the CU
-        if (v == 5 && g->in_dtype == 1 && g->act == 0 && (g->N >= 2048 || g->K >= 2048)) v = 8;
+        // (QuickGELU, an exp2 and a reciprocal per output, is cheap enough to go with them)
+        if (v == 5 && g->in_dtype == 1 && (g->act == 0 || g->act == 2) && (g->N >= 2048 || g->K >= 2048)) v = 8;
         // a short, narrow bf16 product (the attention projection) is mostly its f32 residual traffic: the
         // 128 x 128 pair-fill shape balances 2.3 rounds of 256-row tiles better (4.5 rounds of its own)
         else if (v == 5 && g->in_dtype == 1 && g->act == 0 && g->out_dtype == 0) v = 11;
@@ -221,14 +222,15 @@ static int cu_count() {
     return n;
 }
 
-// Rows the first of two launches covers, or M when the product runs as one launch.  The 256-row shapes keep
-// one (256 x 256) or two (256 x 128) workgroups on a CU, so a product runs in rounds of that many tiles; when
-// the last round is less than 0.6 full (the AlphaCLIP projection and FC2: 2.27 rounds) the rows of the full
-// rounds go out as one launch and the rest as a launch of their own, which the policy then gives a smaller tile.
+// Rows the first of two launches covers, or M when the product runs as one launch.  The 256 x 256 shape keeps
+// one workgroup on a CU, so a product runs in rounds of that many tiles; when the last round is less than 0.6
+// full (the AlphaCLIP FC2: 2.27 rounds) the rows of the full rounds go out as one launch and the rest as a launch
+// of their own, which the policy then gives a smaller tile.  (The same cut on the two-per-CU shapes was slower:
+// 256 x 128 137 -> 149 us, the projection on 128 x 128 with its 4.5 rounds 136 -> 145 us.)
 static int split_rows(const MarsGemm* g, int v) {
     if (!g_gemm_split.load(std::memory_order_relaxed) || g_gemm_variant.load(std::memory_order_relaxed) != 4 || g->nb0 * g->nb1 != 1 || v != 8) return g->M;
-    const int bn = v == 8 ? 256 : 128, slots = cu_count() * (v == 8 ? 1 : 2);
-    const int64_t ntm = (g->M + 255) / 256, ntn = (g->N + bn - 1) / bn, tiles = ntm * ntn;
+    const int slots = cu_count();
+    const int64_t ntm = (g->M + 255) / 256, ntn = (g->N + 255) / 256, tiles = ntm * ntn;
     const int64_t full = tiles / slots, rem = tiles % slots;
     if (full < 1 || full > 4 || rem == 0 || rem * 10 > (int64_t)slots * 6) return g->M;
     const int64_t row_tiles = full * slots / ntn;

@@ -519,25 +519,27 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     else if (inside && aligned && g.act == 3 && !Rb) fast(std::integral_constant<int, 4>{}, I0{});
     else {
         constexpr int EP_LD = FN * 16 + 4;
-        constexpr int CPL = 16 / (int)sizeof(TOUT), LPR = WN / CPL, RPP = 64 / LPR, NPASS = 32 / RPP;
-        static_assert(NWAVES * 32 * EP_LD * 4 <= RING * STAGE, "epilogue staging does not fit");
-        float* ep = (float*)lds + wave * 32 * EP_LD;
+        // slabs of 32 rows per wave where the ring has room for them, of 16 otherwise
+        constexpr int SLAB = NWAVES * 32 * EP_LD * 4 <= RING * STAGE ? 32 : 16;
+        constexpr int CPL = 16 / (int)sizeof(TOUT), LPR = WN / CPL, RPP = 64 / LPR, NPASS = SLAB / RPP;
+        static_assert(NWAVES * SLAB * EP_LD * 4 <= RING * STAGE && NPASS >= 1, "epilogue staging does not fit");
+        float* ep = (float*)lds + wave * SLAB * EP_LD;
         const int ec = (lane % LPR) * CPL, er = lane / LPR;
         const int col = wcol0 + ec;
 #pragma unroll
-        for (int half = 0; half < FM / 2; ++half) {
+        for (int half = 0; half < FM * 16 / SLAB; ++half) {
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
+            for (int mm = 0; mm < SLAB / 16; ++mm)
 #pragma unroll
                 for (int n = 0; n < FN; ++n) {
                     const int c0 = PERM ? 32 * (n >> 1) + 8 * kq + 4 * (n & 1) : 16 * n + 4 * kq;
-                    *(f32x4*)(ep + (mm * 16 + r16) * EP_LD + c0) = acc[half * 2 + mm][n];
+                    *(f32x4*)(ep + (mm * 16 + r16) * EP_LD + c0) = acc[half * (SLAB / 16) + mm][n];
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
             for (int it = 0; it < NPASS; ++it) {
                 const int lr2 = it * RPP + er;
-                const int row = wrow0 + half * 32 + lr2;
+                const int row = wrow0 + half * SLAB + lr2;
                 if (row >= g.M) continue;
 #pragma unroll 1
                 for (int e = 0; e < CPL; ++e) {
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            MARS_STAMP(4 + half)
+            if (half < 4) { MARS_STAMP(4 + half) }
         }
     }
 #ifdef MARS_STAMPS

@@ -45,7 +45,7 @@ def _act(z, act):
     return F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else (F.relu(z) if act == 3 else z))
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [5, 6, 7, 8, 11])
 @pytest.mark.parametrize("act", [1, 3])
 def test_gemm_fast_epilogue_activations(pkg, cuda, variant, act):
     """erf-GELU and ReLU on the register-direct epilogue of the ring kernels (aligned rows, no residual)."""
