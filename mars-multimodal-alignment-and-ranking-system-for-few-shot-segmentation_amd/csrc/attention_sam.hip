@@ -1,0 +1,278 @@
+// Fused attention with the decomposed relative-position bias of the SAM image encoder
+// (segment_anything/modeling/image_encoder.py:224-240, 325-361): softmax(scale q.k + rel_h[q, kh] + rel_w[q, kw]) v
+// for packed projections with head dims padded to 64 or 128, without a score matrix in memory.
+//
+// Same orientation as the 64-wide kernel of attention.hip: a wave owns 16-query blocks and computes S^T = K Q^T
+// with v_mfma_f32_16x16x32_bf16, so a query is a lane column (query = lane & 15), its 64 keys of a tile sit in 16
+// accumulator registers (keys 16 f + 4 g + j for lane group g), the softmax statistics are per-lane scalars and
+// the probabilities are already the B operand of O^T += V^T P^T; V^T fragments come from the row-major V tile
+// through ds_read_b64_tr_b16.  The bias is added to the f32 scores in registers: rel_h / rel_w hold one row of
+// Hk / Wk values per query, and a key k belongs to (k / Wk, k % Wk).  When Wk is the tile width (the global
+// blocks of a 1024-pixel image: 64 x 64 tokens), a tile is one key row: one rel_h value per query and tile and
+// four 16-byte loads of rel_w.  Classic online softmax in the exp2 domain (the bias terms are scaled by log2(e)
+// on the way in, the accumulator by scale * log2(e)).
+#include <type_traits>
+#include "common.h"
+#include "../../include/mars_hip.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+constexpr int KT = 64;                  // keys per tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float rows_max(float x) {       // over lanes l, l^16, l^32, l^48
+    x = fmaxf(x, __shfl_xor(x, 16));
+    return fmaxf(x, __shfl_xor(x, 32));
+}
+__device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 a, f32x4 b) {
+    bf16x8 r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    return r;
+}
+
+// HD: padded head dim (64 or 128); QB: 16-query blocks per wave; four waves per workgroup.  K / V tiles of 64 keys
+// are double buffered and filled by LDS-DMA; a tile's last fragments are in registers before the fill of the next
+// tile starts (hipcc would otherwise drain the DMAs in front of every LDS read that follows one).
+template <int HD, int QB, bool ROWTILE>
+__global__ __launch_bounds__(256, 2) void sam_attn_kernel(const __bf16* __restrict__ qkv, int64_t ld, __bf16* __restrict__ O,
+                                                          int64_t ldo, const float* __restrict__ rel_h,
+                                                          const float* __restrict__ rel_w, int T, int H, int Hk, int Wk,
+                                                          float c2) {
+    constexpr int NW = 4, ROWB = HD * 2, KS = HD / 32, DM = HD / 16, QPB = NW * QB * 16;
+    constexpr int PPO = KT * ROWB / 1024;          // 1-KiB DMA pieces per operand tile
+    constexpr int PPW = 2 * PPO / NW;              // pieces per wave and tile
+    constexpr int RPP = 1024 / ROWB, LPR = ROWB / 16;     // key rows per piece, lanes per key row
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KT * ROWB];      // [buf][K|V]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r16 = lane & 15;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.x * QPB + wave * (QB * 16);
+    const int64_t row_b = ld * 2;                  // bytes per token row of qkv
+    const unsigned char* base = (const unsigned char*)qkv + (int64_t)b * T * row_b + (int64_t)h * ROWB;
+    const int64_t opnd_b = (int64_t)H * ROWB;      // bytes from q to k and from k to v inside a row
+    const bool wave_active = q0 < T;               // trailing waves of the last workgroup only help with the fills
+
+    bf16x8 qf[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 16 + r16, T - 1);
+        const unsigned char* qp = base + (int64_t)qrow * row_b;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 * ks + 16 * g));
+    }
+    // this lane's rows of the bias terms
+    const float* hrow[QB];
+    const float* wrow[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t qr = (int64_t)bh * T + min(q0 + qb * 16 + r16, T - 1);
+        hrow[qb] = rel_h + qr * Hk;
+        wrow[qb] = rel_w + qr * Wk;
+    }
+
+    auto issue_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i, opnd = p / PPO, pp = p % PPO;
+            const int row = RPP * pp + lane / LPR, slot = lane % LPR;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            const int key = min(t * KT + row, T - 1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (1 + opnd) * opnd_b + (int64_t)key * row_b + chunk * 16),
+                                             (lds_ptr_t)(&lds[buf][opnd][pp * 1024]), 16, 0, 0);
+        }
+    };
+
+    f32x4 o[QB][DM + 1];        // un-normalised output, d blocks of 16; [DM]: the running sum of the probabilities
+    float mrun[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        mrun[qb] = -INFINITY;
+#pragma unroll
+        for (int m = 0; m <= DM; ++m) o[qb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const int nt = (T + KT - 1) / KT;
+
+    bf16x8 kf[4][KS], vf[DM][2];
+    const int ksw = (r16 >> 1) & 7;                                   // swizzle term of K rows 16 f + r16
+    const int vq = r16 >> 2, vp = r16 & 3, vsw = (2 * g + (vq >> 1)) & 7;    // of V rows 32 s + 4 g + vq (+ 16)
+
+    auto read_k = [&](int buf) {
+        const unsigned char* kt = &lds[buf][0][0];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kf[f][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt + (16 * f + r16) * ROWB + (((4 * ks + g) ^ ksw) << 4)));
+    };
+    auto read_v = [&](int buf) {
+        const unsigned char* vt = &lds[buf][1][0];
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            // V^T[d = 16 m + 4 vp ..][keys]: byte column 32 m + 8 vp of rows 32 s + 4 g + vq and + 16
+            const int off = (4 * g + vq) * ROWB + (((2 * m + (vp >> 1)) ^ vsw) << 4) + 8 * (vp & 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vt + off + s * 32 * ROWB));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vt + off + s * 32 * ROWB + 16 * ROWB));
+                const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                vf[m][s] = __builtin_bit_cast(bf16x8, r);
+            }
+        }
+    };
+
+    bf16x8 pr[QB][2];           // the tile's probabilities, as the B operands of the two k-steps of P.V
+    // scores, bias, running maximum, probabilities (and the rescale of the accumulators when the maximum moved)
+    auto scores = [&](int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int nfrag = MASKED ? min(4, (T - t * KT + 15) >> 4) : 4;      // fragments with a key < T
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            f32x4 s[4];
+            float hval = 0.f;
+            if constexpr (ROWTILE) hval = hrow[qb][t] * LOG2E;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (!MASKED || f < nfrag) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][ks], qf[qb][ks], acc, 0, 0, 0);
+                    if constexpr (ROWTILE) {
+                        const f32x4 wv = *(const f32x4*)(wrow[qb] + 16 * f + 4 * g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(acc[j], c2, fmaf(wv[j], LOG2E, hval));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int key = min(t * KT + 16 * f + 4 * g + j, T - 1);
+                            const int kh = key / Wk, kw = key - kh * Wk;
+                            acc[j] = fmaf(acc[j], c2, (hrow[qb][kh] + wrow[qb][kw]) * LOG2E);
+                        }
+                    }
+                    if constexpr (MASKED) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (t * KT + 16 * f + 4 * g + j >= T) acc[j] = -INFINITY;
+                    }
+                    s[f] = acc;
+                } else {
+                    s[f] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
+            }
+            float mx = vmax3(s[0][0], s[0][1], s[0][2]);
+            mx = vmax3(mx, s[0][3], s[1][0]);
+            mx = vmax3(mx, s[1][1], s[1][2]);
+            mx = vmax3(mx, s[1][3], s[2][0]);
+            mx = vmax3(mx, s[2][1], s[2][2]);
+            mx = vmax3(mx, s[2][3], s[3][0]);
+            mx = vmax3(mx, s[3][1], s[3][2]);
+            mx = fmaxf(mx, s[3][3]);
+            mx = rows_max(mx);
+            // every tile holds a key < T for every query (the first tile always does), so the maximum is finite
+            const float mnew = fmaxf(mrun[qb], mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+            mrun[qb] = mnew;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[f][j] = __builtin_amdgcn_exp2f(s[f][j] - mnew);
+            if (!__all(alpha == 1.f)) {
+#pragma unroll
+                for (int m = 0; m <= DM; ++m) { o[qb][m][0] *= alpha; o[qb][m][1] *= alpha; o[qb][m][2] *= alpha; o[qb][m][3] *= alpha; }
+            }
+            pr[qb][0] = pack_bf16x8(s[0], s[1]);
+            pr[qb][1] = pack_bf16x8(s[2], s[3]);
+        }
+    };
+    auto accumulate = [&](int t) {
+        const bool second = (T - t * KT) > 32;                   // keys beyond the first 32 of the tile
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+            for (int m = 0; m < DM; ++m) o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][0], pr[qb][0], o[qb][m], 0, 0, 0);
+            o[qb][DM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pr[qb][0], o[qb][DM], 0, 0, 0);
+            if (second) {
+#pragma unroll
+                for (int m = 0; m < DM; ++m) o[qb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[m][1], pr[qb][1], o[qb][m], 0, 0, 0);
+                o[qb][DM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pr[qb][1], o[qb][DM], 0, 0, 0);
+            }
+        }
+    };
+
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // per tile: K fragments -> scores and probabilities; V fragments (in the registers the K fragments no longer
+    // need); only then the fill of the next tile, which lands while P.V runs; wait for it and meet at the barrier
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (wave_active) {
+            read_k(buf);
+            if (t * KT + KT > T) scores(t, std::true_type{});
+            else scores(t, std::false_type{});
+            read_v(buf);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
+        if (wave_active) accumulate(t);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int myq = q0 + qb * 16 + r16;
+        if (myq < T) {
+            const float inv = 1.0f / o[qb][DM][0];
+            __bf16* op = O + ((int64_t)b * T + myq) * ldo + h * HD;
+#pragma unroll
+            for (int m = 0; m < DM; ++m) {
+                bf16x4 v;
+                v[0] = (__bf16)(o[qb][m][0] * inv); v[1] = (__bf16)(o[qb][m][1] * inv);
+                v[2] = (__bf16)(o[qb][m][2] * inv); v[3] = (__bf16)(o[qb][m][3] * inv);
+                *(bf16x4*)(op + 16 * m + 4 * g) = v;
+            }
+        }
+    }
+}
+
+template <int HD, int QB>
+int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w, int nb, int T,
+           int H, int Hk, int Wk, float c2, hipStream_t s) {
+    constexpr int QPB = 4 * QB * 16;
+    dim3 grid((T + QPB - 1) / QPB, nb * H), block(256);
+    // one key row per tile: no division, and whole 16-byte loads of rel_w (rows of 64 floats are 16-byte aligned)
+    if (Wk == KT && T == Hk * Wk && ((uintptr_t)rel_w % 16) == 0)
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, true>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2);
+    else
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, false>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
+                                int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream) {
+    MARS_CHECK(qkv && O && rel_h && rel_w, "sam_attn: null pointer");
+    MARS_CHECK(nb > 0 && T > 0 && H > 0 && Hk > 0 && Wk > 0 && Hk * Wk >= T, "sam_attn: bad shape nb=%d T=%d H=%d Hk=%d Wk=%d", nb, T, H, Hk, Wk);
+    MARS_CHECK(hdp == 64 || hdp == 128, "sam_attn: padded head dim %d (64 or 128)", hdp);
+    MARS_CHECK(ld >= 3 * (int64_t)H * hdp && ld % 8 == 0 && ldo >= (int64_t)H * hdp && ldo % 4 == 0, "sam_attn: row strides");
+    MARS_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)O % 8) == 0, "sam_attn: alignment");
+    MARS_CHECK((int64_t)nb * H <= 65535, "sam_attn: too many (image, head) pairs for one launch");
+    const float c2 = scale * 1.4426950408889634f;
+    if (hdp == 64) return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+    return launch<128, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+}

@@ -562,6 +562,19 @@ def relpos_bias(qkv: torch.Tensor, B: int, T: int, H: int, hd: int, hdp: int, gw
                                             dt(qkv), stream()), "marship_relpos_bias")
 
 
+def sam_attn(qkv: torch.Tensor, out: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, nb: int, T: int, H: int, hdp: int,
+             Hk: int, Wk: int, scale: float):
+    """out[nb*T, H*hdp] = attention of packed bf16 qkv rows with the decomposed relative-position bias, fused."""
+    _dev(qkv, out, rel_h, rel_w)
+    _req(qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and qkv.dim() == 2 and out.dim() == 2, "sam_attn: bf16 rows")
+    _req(qkv.stride(1) == 1 and out.stride(1) == 1 and qkv.shape[0] >= nb * T and out.shape[0] >= nb * T, "sam_attn: rows")
+    _req(qkv.shape[1] >= 3 * H * hdp and out.shape[1] >= H * hdp, "sam_attn: columns")
+    _req(rel_h.dtype == torch.float32 and rel_w.dtype == torch.float32 and rel_h.numel() >= nb * H * T * Hk and rel_w.numel() >= nb * H * T * Wk,
+         "sam_attn: bias terms")
+    hip.check(hip.lib().marship_sam_attn(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(rel_h), ptr(rel_w), nb, T, H, hdp, Hk, Wk,
+                                         scale, stream()), "marship_sam_attn")
+
+
 def softmax_bias_rows(S: torch.Tensor, P: torch.Tensor, nrows: int, T: int, rel_h=None, rel_w=None, Hk: int = 0, Wk: int = 0):
     _dev(S, P, rel_h, rel_w)
     _req(S.dtype == torch.float32 and S.stride(-1) == 1 and P.stride(-1) == 1, "softmax_bias_rows: layout")

@@ -17,6 +17,8 @@ import math
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
+import os
+
 import torch
 
 from .. import ops, resample
@@ -144,6 +146,9 @@ class ImageEncoderViT:
         self.neck2 = Lin(sd[prefix + ".neck.2.weight"].permute(0, 2, 3, 1).reshape(C, 9 * C), None, dtype, dev)
         self.neck3 = (_dev_f32(sd[prefix + ".neck.3.weight"], dev), _dev_f32(sd[prefix + ".neck.3.bias"], dev))
         self._attn = _Attn(dev, dtype)
+        # bf16 towers: scores, bias, softmax and P.V in one kernel (no [heads, T, T] score matrix); MARS_FLASH=0 or
+        # an f32 tower keep the three-launch form
+        self.fused_attention = dtype == torch.bfloat16 and hdp in (64, 128) and os.environ.get("MARS_FLASH", "1") != "0"
         self._build_index_maps()
         self._mean = torch.tensor(PIXEL_MEAN, dtype=torch.float32, device=dev)
         self._std = torch.tensor(PIXEL_STD, dtype=torch.float32, device=dev)
@@ -207,7 +212,10 @@ class ImageEncoderViT:
             rel_w = self._rel_buf("w", nb * H * Tt * gw)
             ops.relpos_bias(qkv, nb, Tt, H, hd, hdp, gw, b.Rh, b.Rw, rel_h, rel_w)
             ao = w["ao"][:rows]
-            self._attn.run(qkv, 0, qkv, H * hdp, qkv, 2 * H * hdp, ao, nb, H, Tt, Tt, hdp, hd ** -0.5, rel=(rel_h, rel_w, Tt // gw, gw))
+            if self.fused_attention:
+                ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5)
+            else:
+                self._attn.run(qkv, 0, qkv, H * hdp, qkv, 2 * H * hdp, ao, nb, H, Tt, Tt, hdp, hd ** -0.5, rel=(rel_h, rel_w, Tt // gw, gw))
             if b.ws > 0:
                 ops.gather_rows(ao, self.unpart_idx, w["aou"])
                 ao = w["aou"]

@@ -360,3 +360,54 @@ def test_generator_small_regions_and_coco_rle(pkg):
             assert n == 1 or sizes.min() >= area               # no island below the area is left (one may stay if all were)
         else:
             assert a["bbox"] == plain[i]["bbox"]
+
+
+@pytest.mark.parametrize("nb,gh,gw,H,hd,hdp", [(1, 64, 64, 2, 80, 128), (1, 64, 64, 3, 64, 64), (3, 14, 14, 2, 64, 64),
+                                                  (2, 14, 14, 2, 80, 128), (1, 10, 10, 1, 64, 64), (2, 5, 13, 2, 48, 64)])
+def test_fused_attention_with_relpos_bias(pkg, nb, gh, gw, H, hd, hdp):
+    """marship_sam_attn against softmax(scale q.k + rel_h + rel_w) v in f64 on the same bf16 operands: global
+    blocks of a 1024-pixel image (one key row per tile), windows, ragged last tiles, padded head dims."""
+    ops = pkg.ops
+    T = gh * gw
+    g = torch.Generator().manual_seed(nb * 1000 + T + hdp)
+    qkv = torch.zeros(nb * T, 3 * H * hdp, dtype=torch.bfloat16)
+    val = torch.randn(nb * T, 3, H, hd, generator=g)
+    val[:, 0] *= 2.0                                                   # scores a few units wide
+    qkv.view(nb * T, 3, H, hdp)[..., :hd] = val.to(torch.bfloat16)
+    rel_h = torch.randn(nb * H, T, gh, generator=g) * 1.5
+    rel_w = torch.randn(nb * H, T, gw, generator=g) * 1.5
+    scale = hd ** -0.5
+    q, k, v = (qkv.view(nb, T, 3, H, hdp)[:, :, i].permute(0, 2, 1, 3).double() for i in range(3))      # [nb, H, T, hdp]
+    kh, kw = torch.arange(T) // gw, torch.arange(T) % gw
+    bias = rel_h.double().view(nb, H, T, gh)[..., kh] + rel_w.double().view(nb, H, T, gw)[..., kw]
+    P = torch.softmax(scale * q @ k.transpose(-1, -2) + bias, dim=-1)
+    ref = (P @ v).permute(0, 2, 1, 3).reshape(nb * T, H * hdp)
+    out = torch.full((nb * T, H * hdp), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.sam_attn(qkv.cuda(), out, rel_h.cuda(), rel_w.cuda(), nb, T, H, hdp, gh, gw, scale)
+    assert bool(torch.isfinite(out.float()).all())
+    err = (out.double().cpu() - ref).abs()
+    # the probabilities are rounded to bf16 before P.V and the result once more
+    assert float(err.max()) < 0.02 * float(ref.abs().max()), float(err.max())
+    if hdp > hd:
+        assert float(out.view(nb * T, H, hdp)[..., hd:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("arch", ["tiny", "tiny80"])
+def test_encoder_fused_attention_agrees_with_three_launch_form(pkg, arch):
+    """bf16 encoder with the fused attention against the same encoder with scores, softmax and P.V as three
+    launches: both are one bf16 rounding per operand away from the f32 encoder."""
+    sa = pkg.segment_anything
+    cfg = pkg.synth.SAM_ARCHS[arch]
+    sd = pkg.synth.sam_state_dict(cfg, seed=5)
+    img = GOLD[f"sam_{arch}_image"]
+    ref = torch.as_tensor(GOLD[f"sam_{arch}_features"]).cuda()
+    feats = {}
+    for fused in (True, False):
+        sam = sa.sam_model_registry[arch](state_dict=sd, device="cuda", dtype=torch.bfloat16)
+        assert sam.image_encoder.fused_attention
+        sam.image_encoder.fused_attention = fused
+        pred = sa.SamPredictor(sam)
+        pred.set_image(img)
+        feats[fused] = pred.features.float().clone()
+    e_fused, e_three = maxdiff(feats[True], ref), maxdiff(feats[False], ref)
+    assert e_fused < 1.5 * e_three + 1e-3 * float(ref.abs().max()), (e_fused, e_three)

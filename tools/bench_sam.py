@@ -41,6 +41,13 @@ def main():
     img = rng.integers(0, 256, size=(a.size[0], a.size[1], 3), dtype=np.uint8)
     pred = sa.SamPredictor(sam)
     print(f"set_image: {timed(lambda: pred.set_image(img), a.reps):.2f} ms", flush=True)
+    enc = sam.image_encoder
+    if getattr(enc, "fused_attention", False):
+        enc.fused_attention = False
+        print(f"set_image with scores / softmax / P.V as three launches: {timed(lambda: pred.set_image(img), a.reps):.2f} ms "
+              f"(workspace {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB)", flush=True)
+        enc.fused_attention = True
+        pred.set_image(img)
     pts = torch.rand(64, 1, 2, device="cuda") * 1000
     lab = torch.ones(64, 1, dtype=torch.int32, device="cuda")
     print(f"predict_torch (64 points, 3 masks each, logits at {a.size}): "
