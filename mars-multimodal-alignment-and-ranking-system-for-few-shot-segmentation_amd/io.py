@@ -4,7 +4,7 @@
   (/root/reference/main_MARS.py:62).  ``load_proposals`` reads those with ``weights_only=True`` and also a
   bit-packed form (``.mprop``: 32x smaller on disk and over PCIe, unpacked on the GPU).
 * checkpoints: plain state dicts (optionally wrapped in ``{"model": ...}`` / ``{"state_dict": ...}``, optionally
-  with a ``module.`` prefix), read with ``weights_only=True``; TorchScript archives are refused, nothing in a
+  with a ``module.`` prefix), read with ``weights_only=True``; of TorchScript archives only the tensors are read (no code of the archive runs), nothing in a
   file is ever executed (/root/reference/utils/backbone_loader.py:17-52, segment_anything/build_sam.py:103-106).
 * split lists: ``read_plain_pickle`` rebuilds containers of plain values from a pickle's opcode listing and
   refuses every opcode that would import or call something, for split files like the reference's
@@ -71,9 +71,11 @@ def load_proposals(path: str, device) -> torch.Tensor:
 def load_state_dict(path: str) -> Dict[str, torch.Tensor]:
     if zipfile.is_zipfile(path):
         with zipfile.ZipFile(path) as z:
-            if any(n.endswith("constants.pkl") or "/code/" in n for n in z.namelist()):
-                raise ValueError(f"{path} is a TorchScript archive; export its state_dict() to a plain checkpoint first "
-                                 "(loading it would run code from the file)")
+            scripted = any(n.endswith("constants.pkl") or "/code/" in n for n in z.namelist())
+        if scripted:
+            # the archives OpenAI publishes CLIP in (clip/clip.py:95-150 loads them with torch.jit.load and takes
+            # state_dict()): the tensors are taken out of the archive's data pickle without running any of it
+            return read_torchscript_state_dict(path)
     sd = torch.load(path, map_location="cpu", weights_only=True)
     for key in ("model", "state_dict", "model_state_dict"):
         if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
@@ -95,6 +97,12 @@ def read_plain_pickle(path: str, max_bytes: int = 1 << 30) -> Any:
         data = f.read(max_bytes + 1)
     if len(data) > max_bytes:
         raise ValueError(f"{path}: larger than {max_bytes} bytes")
+    return _plain_objects(data, path, None)
+
+
+def _plain_objects(data: bytes, path: str, extra) -> Any:
+    """The object a pickle describes, from its opcode listing.  ``extra(name, arg, stack, pop_mark)`` may take the
+    opcodes that are outside plain data (it returns False for what it does not take: those are refused)."""
     stack, memo = [], {}
 
     def pop_mark():
@@ -170,6 +178,107 @@ def read_plain_pickle(path: str, max_bytes: int = 1 << 30) -> Any:
             pop_mark()
         elif n == "DUP":
             stack.append(stack[-1])
+        elif extra is not None and extra(n, arg, stack, pop_mark):
+            pass
         else:
             raise ValueError(f"{path}: opcode {n} is outside plain data (it would import or construct an object); refused")
     raise ValueError(f"{path}: truncated pickle")
+
+
+# ------------------------------------------------------------------ TorchScript archives, tensors only
+class _Named:
+    """A global a pickle names (never imported), or an instance of one with the state the pickle gives it."""
+
+    def __init__(self, module: str, name: str, instance: bool = False):
+        self.module, self.name, self.instance, self.state = module, name, instance, None
+
+
+_STORAGE_DTYPES = {
+    "FloatStorage": torch.float32, "HalfStorage": torch.float16, "BFloat16Storage": torch.bfloat16, "DoubleStorage": torch.float64,
+    "LongStorage": torch.int64, "IntStorage": torch.int32, "ShortStorage": torch.int16, "CharStorage": torch.int8,
+    "ByteStorage": torch.uint8, "BoolStorage": torch.bool,
+}
+
+
+def read_torchscript_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """``torch.jit.load(path).state_dict()`` without loading the module: the archive's ``data.pkl`` is walked opcode by
+    opcode (``pickletools.genops``), the classes it names stay names, and the only calls honoured are the ones
+    written out here - ``torch._utils._rebuild_tensor_v2`` on a storage record of the archive (a strided view of the
+    bytes of ``data/<key>``) and an empty ``collections.OrderedDict``.  Attribute paths of the module tree become
+    the keys; anything else the pickle would import or call raises ``ValueError``."""
+    with zipfile.ZipFile(path) as z:
+        names = z.namelist()
+        pkl = [n for n in names if n.endswith("/data.pkl") and n.count("/") == 1]
+        if len(pkl) != 1:
+            raise ValueError(f"{path}: not a TorchScript archive (no data.pkl)")
+        root = pkl[0][: -len("data.pkl")]
+        if root + "byteorder" in names and z.read(root + "byteorder").strip() not in (b"little", b""):
+            raise ValueError(f"{path}: big-endian archive")
+        storages: Dict[str, torch.Tensor] = {}
+
+        def storage(rec) -> torch.Tensor:
+            if not (isinstance(rec, tuple) and len(rec) == 5 and rec[0] == "storage" and isinstance(rec[1], _Named)
+                    and rec[1].module == "torch" and rec[1].name in _STORAGE_DTYPES and isinstance(rec[2], str)):
+                raise ValueError(f"{path}: persistent id {rec!r} is not a tensor storage; refused")
+            key, dtype, numel = rec[2], _STORAGE_DTYPES[rec[1].name], int(rec[4])
+            if key not in storages:
+                name = root + "data/" + key
+                if name not in names:
+                    raise ValueError(f"{path}: storage {key} is missing from the archive")
+                raw = bytearray(z.read(name))
+                if len(raw) < numel * torch.empty(0, dtype=dtype).element_size():
+                    raise ValueError(f"{path}: storage {key} is shorter than its record")
+                storages[key] = torch.frombuffer(raw, dtype=dtype, count=numel) if numel else torch.empty(0, dtype=dtype)
+            return storages[key]
+
+        def extra(n, arg, stack, pop_mark) -> bool:
+            if n == "GLOBAL":
+                module, name = arg.split(" ", 1)
+                stack.append(_Named(module, name))
+            elif n == "STACK_GLOBAL":
+                name, module = stack.pop(), stack.pop()
+                stack.append(_Named(module, name))
+            elif n == "BINPERSID":
+                stack.append(storage(stack.pop()))
+            elif n == "NEWOBJ":
+                args, cls = stack.pop(), stack.pop()
+                if not (isinstance(cls, _Named) and not cls.instance and cls.module.split(".")[0] == "__torch__" and args == ()):
+                    raise ValueError(f"{path}: object of {getattr(cls, 'module', cls)!r} is not a scripted class; refused")
+                stack.append(_Named(cls.module, cls.name, instance=True))
+            elif n == "BUILD":
+                state = stack.pop()
+                if not (isinstance(stack[-1], _Named) and stack[-1].instance):
+                    raise ValueError(f"{path}: state for something that is not a scripted object; refused")
+                stack[-1].state = state
+            elif n == "REDUCE":
+                args, fn = stack.pop(), stack.pop()
+                what = (fn.module, fn.name) if isinstance(fn, _Named) and not fn.instance else None
+                if what == ("collections", "OrderedDict") and args == ():
+                    stack.append({})
+                elif what == ("torch._utils", "_rebuild_tensor_v2") and len(args) >= 4 and torch.is_tensor(args[0]):
+                    st, offset, size, stride = args[0], int(args[1]), tuple(int(v) for v in args[2]), tuple(int(v) for v in args[3])
+                    need = offset + sum((d - 1) * k for d, k in zip(size, stride)) + 1 if all(d > 0 for d in size) else 0
+                    if offset < 0 or any(k < 0 for k in stride) or need > st.numel():
+                        raise ValueError(f"{path}: tensor view outside its storage; refused")
+                    stack.append(torch.as_strided(st, size, stride, offset))
+                else:
+                    raise ValueError(f"{path}: call of {what or fn!r} is not part of a tensor record; refused")
+            else:
+                return False
+            return True
+
+        module = _plain_objects(z.read(pkl[0]), path, extra)
+    out: Dict[str, torch.Tensor] = {}
+
+    def walk(obj, prefix: str):
+        if torch.is_tensor(obj):
+            out[prefix[:-1]] = obj.clone()
+        elif isinstance(obj, _Named) and obj.instance and isinstance(obj.state, dict):
+            for k, v in obj.state.items():
+                if isinstance(k, str):
+                    walk(v, prefix + k + ".")
+
+    walk(module, "")
+    if not out:
+        raise ValueError(f"{path}: no tensors found in the archive's module")
+    return out

@@ -59,10 +59,80 @@ def test_state_dict_reader(mods, tmp_path):
     torch.save({"a": 1}, p)
     with pytest.raises(ValueError):
         pio.load_state_dict(str(p))
-    script = tmp_path / "scripted.pt"
-    torch.jit.save(torch.jit.script(torch.nn.Linear(2, 2)), str(script))
-    with pytest.raises(ValueError, match="TorchScript"):
-        pio.load_state_dict(str(script))
+
+
+class _Leaf(torch.nn.Module):
+    def __init__(self, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.lin = torch.nn.Linear(3, 3)
+        self.lin.weight.data = torch.randn(3, 3, generator=g)
+        self.register_buffer("scale", torch.randn(3, generator=g).half())
+        self.register_buffer("steps", torch.arange(3))
+
+    def forward(self, x):
+        return self.lin(x) * self.scale.float() + self.steps.float()
+
+
+class _Tree(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.first = _Leaf(1)
+        self.logit_scale = torch.nn.Parameter(torch.tensor(2.5))
+        self.proj = torch.nn.Parameter(torch.randn(3, 2, generator=torch.Generator().manual_seed(2)).t().contiguous().t())   # strided
+        self.blocks = torch.nn.Sequential(_Leaf(3), _Leaf(4))
+
+    def forward(self, x):
+        return self.blocks(self.first(x)) @ self.proj * self.logit_scale
+
+
+def test_torchscript_archive_tensors_without_running_it(mods, tmp_path):
+    """The format OpenAI publishes CLIP in (/root/reference/clip/clip.py:95-150 calls torch.jit.load on it and takes
+    state_dict()): scripted and traced archives give the module's state dict, read from the opcode listing."""
+    pio, _ = mods
+    m = _Tree().eval()
+    want = m.state_dict()
+    for name, mod in (("scripted", torch.jit.script(m)), ("traced", torch.jit.trace(m, torch.zeros(1, 3)))):
+        p = tmp_path / f"{name}.pt"
+        torch.jit.save(mod, str(p))
+        for got in (pio.read_torchscript_state_dict(str(p)), pio.load_state_dict(str(p))):
+            assert set(got) == set(want), (sorted(got), sorted(want))
+            for k in want:
+                assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape and torch.equal(got[k], want[k]), k
+
+
+def test_torchscript_archive_with_a_call_in_it_is_refused(mods, tmp_path):
+    """An archive whose data pickle imports or calls anything but the tensor records is refused, and nothing runs."""
+    import zipfile
+    pio, _ = mods
+    marker = tmp_path / "ran"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    good = tmp_path / "good.pt"
+    torch.jit.save(torch.jit.script(torch.nn.Linear(2, 2)), str(good))
+    cases = {
+        "call": pickle.dumps(Evil(), protocol=2),
+        "foreign_object": pickle.dumps(pytest.raises, protocol=2),          # a global that is not a scripted class
+    }
+    for name, payload in cases.items():
+        bad = tmp_path / f"{name}.pt"
+        with zipfile.ZipFile(good) as zi, zipfile.ZipFile(bad, "w") as zo:
+            for item in zi.namelist():
+                zo.writestr(item, payload if item.endswith("/data.pkl") else zi.read(item))
+        with pytest.raises(ValueError):
+            pio.load_state_dict(str(bad))
+    assert not marker.exists()
+    # a tensor record that reaches beyond its storage: the archive's own records with one storage cut short
+    short = tmp_path / "short.pt"
+    with zipfile.ZipFile(good) as zi, zipfile.ZipFile(short, "w") as zo:
+        for item in zi.namelist():
+            zo.writestr(item, zi.read(item)[:4] if item.endswith("/data/0") else zi.read(item))
+    with pytest.raises(ValueError):
+        pio.read_torchscript_state_dict(str(short))
+    assert pio.read_torchscript_state_dict(str(good))["weight"].shape == (2, 2)
 
 
 def _write_images(root, names, rng, size=(40, 30)):
