@@ -397,27 +397,45 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                 rstd_[m] = st.y;
             }
         }
-        TOUT* cp = Cb + (int64_t)(wrow0 + r16) * g.ldc + lcol;
+        // Lanes of a C^T fragment that follow one another hold different ROWS, so a 16-byte access per lane reaches
+        // memory as 64 requests of 16 bytes; four consecutive lanes on 64 consecutive bytes of one row go out as one
+        // request and move 1.5-1.8 times the bytes per cycle (tools/diag_store.hip).  The residual is therefore
+        // loaded, and the result stored, in that other lane order - lane L on row L >> 2, 16-byte piece L & 3 of the
+        // fragment row - and moved between the two orders with ds_bpermute, four dwords per access.
+        const int r16s = lane >> 2, kqs = lane & 3;
+        const int to_store = (((lane & 3) << 4) | (lane >> 2)) << 2;     // lane L of the store order takes fragment lane (L & 3, L >> 2)
+        const int to_frag = (((lane & 15) << 2) | (lane >> 4)) << 2;      // fragment lane (kq, r16) takes lane 4 r16 + kq
+        auto xlane = [&](uint4 v, int idx) {
+            uint4 r;
+            r.x = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)v.x);
+            r.y = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)v.y);
+            r.z = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)v.z);
+            r.w = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)v.w);
+            return r;
+        };
+        const int lcol_s = wcol0 + VW * kqs;
+        TOUT* cp = Cb + (int64_t)(wrow0 + r16s) * g.ldc + lcol_s;
         // residual rows are requested PD - 1 fragment rows ahead of their use, in the registers the
         // operand fragments no longer need; a load issued after a store would retire behind it
         constexpr int PD = 3;
-        f32x4 res[PLANES ? 1 : PD][NV][VW / 4];
-        bf16x8 rhi[PLANES ? PD : 1][NV], rlo[PLANES ? PD : 1][NV];
-        const float* rp = (MODE == 2 && !PLANES) ? Rb + (int64_t)(wrow0 + r16) * g.ldr + lcol : nullptr;
-        __bf16* hp = PLANES ? (__bf16*)g.ln_copy + (int64_t)(wrow0 + r16) * g.ldcopy + lcol : nullptr;
-        __bf16* lp = PLANES ? (__bf16*)g.ln_lo + (int64_t)(wrow0 + r16) * g.ldcopy + lcol : nullptr;
+        uint4 res[PLANES ? 1 : PD][NV][VW / 4];
+        uint4 rhi[PLANES ? PD : 1][NV], rlo[PLANES ? PD : 1][NV];
+        const float* rp = (MODE == 2 && !PLANES) ? Rb + (int64_t)(wrow0 + r16s) * g.ldr + lcol_s : nullptr;
+        __bf16* hp = PLANES ? (__bf16*)g.ln_copy + (int64_t)(wrow0 + r16s) * g.ldcopy + lcol_s : nullptr;
+        __bf16* lp = PLANES ? (__bf16*)g.ln_lo + (int64_t)(wrow0 + r16s) * g.ldcopy + lcol_s : nullptr;
         const int rows_left = g.M - (wrow0 + r16);         // fragment row m of this lane exists iff 16 m < rows_left
+        const int rows_left_s = g.M - (wrow0 + r16s);      // the same for the row this lane loads and stores
         auto load_res = [&](int m) {
-            if (16 * m < rows_left) {
+            if (16 * m < rows_left_s) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     if constexpr (PLANES) {
-                        rhi[m % PD][v] = *(const bf16x8*)(hp + (int64_t)m * 16 * g.ldcopy + v * VS);
-                        rlo[m % PD][v] = *(const bf16x8*)(lp + (int64_t)m * 16 * g.ldcopy + v * VS);
+                        rhi[m % PD][v] = *(const uint4*)(hp + (int64_t)m * 16 * g.ldcopy + v * VS);
+                        rlo[m % PD][v] = *(const uint4*)(lp + (int64_t)m * 16 * g.ldcopy + v * VS);
                     } else {
 #pragma unroll
                         for (int q = 0; q < VW / 4; ++q)
-                            res[m % PD][v][q] = *(const f32x4*)(rp + (int64_t)m * 16 * g.ldr + v * VS + 4 * q);
+                            res[m % PD][v][q] = *(const uint4*)(rp + (int64_t)m * 16 * g.ldr + v * VS + 4 * q);
                     }
                 }
             }
@@ -435,6 +453,20 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 float x[VW];
+                // the residual of this fragment row, brought into the fragment's lane order
+                float radd[VW];
+                if constexpr (PLANES) {
+                    const bf16x8 fh = __builtin_bit_cast(bf16x8, xlane(rhi[m % PD][v], to_frag));
+                    const bf16x8 fl = __builtin_bit_cast(bf16x8, xlane(rlo[m % PD][v], to_frag));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) radd[e] = (float)fh[e] + (float)fl[e];
+                } else if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int q = 0; q < VW / 4; ++q) {
+                        const f32x4 f = __builtin_bit_cast(f32x4, xlane(res[m % PD][v][q], to_frag));
+                        radd[4 * q] = f[0]; radd[4 * q + 1] = f[1]; radd[4 * q + 2] = f[2]; radd[4 * q + 3] = f[3];
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
                     const float a0 = PERM ? acc[m][2 * v + (e >> 2)][e & 3] : acc[m][v][e & 3];
@@ -445,8 +477,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                     if constexpr (MODE == 3) y = act_fn3<FAST>(y, 1);
                     if constexpr (MODE == 4) y = fmaxf(y, 0.f);
                     y *= gam_[v][e];
-                    if constexpr (PLANES) y += (float)rhi[m % PD][v][e] + (float)rlo[m % PD][v][e];
-                    else if constexpr (MODE == 2) y += res[m % PD][v][e >> 2][e & 3];
+                    if constexpr (MODE == 2) y += radd[e];
                     x[e] = y;
                     if constexpr (LN == 1) {
                         rs += y;
@@ -454,25 +485,30 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
                     }
                 }
                 TOUT* c = cp + (int64_t)m * 16 * g.ldc + v * VS;
-                if (16 * m < rows_left) {
-                    if constexpr (LN == 1) {
-                        bf16x8 oh, ol;
+                if constexpr (LN == 1) {
+                    bf16x8 oh, ol;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            oh[e] = (__bf16)x[e];
-                            ol[e] = (__bf16)(x[e] - (float)oh[e]);
-                        }
-                        *(bf16x8*)(hp + (int64_t)m * 16 * g.ldcopy + v * VS) = oh;
-                        *(bf16x8*)(lp + (int64_t)m * 16 * g.ldcopy + v * VS) = ol;
-                    } else if constexpr (sizeof(TOUT) == 4) {
-#pragma unroll
-                        for (int q = 0; q < VW / 4; ++q) *(f32x4*)(c + 4 * q) = (f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-                    } else {
-                        bf16x8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[e];
-                        *(bf16x8*)c = o;
+                    for (int e = 0; e < 8; ++e) {
+                        oh[e] = (__bf16)x[e];
+                        ol[e] = (__bf16)(x[e] - (float)oh[e]);
                     }
+                    const uint4 sh = xlane(__builtin_bit_cast(uint4, oh), to_store), sl = xlane(__builtin_bit_cast(uint4, ol), to_store);
+                    if (16 * m < rows_left_s) {
+                        *(uint4*)(hp + (int64_t)m * 16 * g.ldcopy + v * VS) = sh;
+                        *(uint4*)(lp + (int64_t)m * 16 * g.ldcopy + v * VS) = sl;
+                    }
+                } else if constexpr (sizeof(TOUT) == 4) {
+#pragma unroll
+                    for (int q = 0; q < VW / 4; ++q) {
+                        const uint4 sv = xlane(__builtin_bit_cast(uint4, (f32x4){x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]}), to_store);
+                        if (16 * m < rows_left_s) *(uint4*)(c + 4 * q) = sv;
+                    }
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[e];
+                    const uint4 sv = xlane(__builtin_bit_cast(uint4, o), to_store);
+                    if (16 * m < rows_left_s) *(uint4*)c = sv;
                 }
             }
             if constexpr (LN == 1) {
