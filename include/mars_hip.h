@@ -71,11 +71,11 @@ int marship_gemm(const MarsGemm* g, void* stream);
  * one. 0 = register-staged 128x128 tile, 1 = LDS-DMA 128x128, 2 = LDS-DMA 256x128,
  * 3 = LDS-DMA ring 256x256, 4 = chosen by shape (default), 5 = ring 256x128, 6 = ring 128x128,
  * 7 = ring 64x128, 8 = ring 256x256 with pair fills, 9 / 10 / 11 = 128x128 (eight slots), 64x128 (six slots),
- * 128x128 (four slots) with pair fills.  Process-wide: every later marship_gemm of every thread reads it (a
+ * 128x128 (four slots) with pair fills, 12 = 8 as persistent workgroups.  Process-wide: every later marship_gemm of every thread reads it (a
  * relaxed atomic: no data race, but no ordering with products other threads are launching) - set it at
  * start-up or while no other thread launches products.  The same holds for marship_set_gemm_split. */
 int marship_set_gemm_variant(int variant);
-/* The variant marship_gemm would run for this product (5, 6, 7, 8, 10 or 11 under "chosen by shape"); used by
+/* The variant marship_gemm would run for this product (5, 6, 7, 8, 10, 11 or 12 under "chosen by shape"); used by
  * the benchmark to attribute launch times to kernels.  No reference counterpart. */
 int marship_gemm_variant_for(const MarsGemm* g);
 /* Tuning hook (no reference counterpart): under "chosen by shape" a tall unbatched product whose tiles would
@@ -84,6 +84,11 @@ int marship_gemm_variant_for(const MarsGemm* g);
  * previous setting.  marship_gemm_split_rows returns r (M when the product is not split). */
 int marship_set_gemm_split(int on);
 int marship_gemm_split_rows(const MarsGemm* g);
+/* Tuning hook (no reference counterpart): the number of workgroups a persistent launch (variant 12: every
+ * workgroup walks the tiles b, b + slots, ... and fills the ring for its next tile under the epilogue of the one
+ * in hand) uses; 0 = one per CU (default).  Rounded down to a multiple of 8 above 8.  Process-wide like the two
+ * hooks above; returns the previous setting. */
+int marship_set_gemm_slots(int slots);
 
 /* ---- ViT glue ------------------------------------------------------------------ */
 /* nn.LayerNorm over the last dim (dinov2 vision_transformer.py:97 eps 1e-6; clip/model.py:265-271

@@ -16,6 +16,7 @@
 // 16 rows a ds_read_b128 lane group touches land on 16 distinct 16-byte bank slots.
 // Out-of-range rows are clamped on the source address (results never stored).
 #include <atomic>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/mars_hip.h"
 
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(THREADS) void gemm_tn_kernel(MarsGemm g) {
 }  // namespace
 
 void mars_gemm_glds_launch(const MarsGemm& g, hipStream_t s, int variant);
-void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape);
+void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape, int slots);
 // The two tuning hooks below set process-wide state that every later marship_gemm call of every thread reads.
 // They are relaxed atomics: reading them while another thread sets them is not a data race, but a setter is not
 // ordered with products other threads are launching - set them at start-up, or while nobody else launches.
@@ -170,9 +171,10 @@ static std::atomic<int> g_gemm_variant{4};
 // 3 = LDS-DMA ring 256x256, 4 = choose by shape (default), 5 = LDS-DMA ring 256x128,
 // 6 = LDS-DMA ring 128x128, 7 = LDS-DMA ring 64x128, 8 = LDS-DMA ring 256x256 with pair fills,
 // 9 = 128x128 with pair fills and eight slots, 10 = 64x128 with pair fills and six slots,
-// 11 = 128x128 with pair fills and four slots.
+// 11 = 128x128 with pair fills and four slots, 12 = 8 as persistent workgroups (one per CU, each filling the
+// ring for its next tile under the epilogue of the one in hand).
 extern "C" int marship_set_gemm_variant(int v) {
-    if (v >= 0 && v <= 11) return g_gemm_variant.exchange(v, std::memory_order_relaxed);
+    if (v >= 0 && v <= 12) return g_gemm_variant.exchange(v, std::memory_order_relaxed);
     return g_gemm_variant.load(std::memory_order_relaxed);
 }
 
@@ -182,7 +184,15 @@ static std::atomic<int> g_gemm_split{1};
 extern "C" int marship_set_gemm_split(int on) { return g_gemm_split.exchange(on != 0, std::memory_order_relaxed); }
 
 // the kernel variant the launch policy picks for a product (the variant set by the tuning hook, or, for
-// "choose by shape", the ring shape: 5, 6, 7, 8, 10 or 11)
+// "choose by shape", the ring shape: 5, 6, 7, 8, 10, 11 or 12)
+// MARS_GEMM_PERSIST=1 runs the 256 x 256 shape as persistent workgroups (variant 12; read once, for A/B runs).
+// Off by default: per product it is within 2 % of one workgroup per tile either way, and a whole step of the
+// benchmark is 4 % slower with it (44.2 against 42.5 ms, three interleaved runs).
+static bool persist_default() {
+    static const bool on = [] { const char* e = getenv("MARS_GEMM_PERSIST"); return e && e[0] == '1'; }();
+    return on;
+}
+
 static int pick_variant(const MarsGemm* g) {
     int v = g_gemm_variant.load(std::memory_order_relaxed);
     if (v == 4) {
@@ -194,7 +204,8 @@ static int pick_variant(const MarsGemm* g) {
         // per 128 bytes of K); an activation epilogue, or a short product whose time is mostly its residual
         // traffic, is better hidden behind the second 256 x 128 workgroup of the CU
         // (QuickGELU, an exp2 and a reciprocal per output, is cheap enough to go with them)
-        if (v == 5 && g->in_dtype == 1 && (g->act == 0 || g->act == 2) && (g->N >= 2048 || g->K >= 2048)) v = 8;
+        // (as persistent workgroups when the product is one batch entry)
+        if (v == 5 && g->in_dtype == 1 && (g->act == 0 || g->act == 2) && (g->N >= 2048 || g->K >= 2048)) v = g->nb0 * g->nb1 == 1 && persist_default() ? 12 : 8;
         // a short, narrow bf16 product (the attention projection) is mostly its f32 residual traffic: the
         // 128 x 128 pair-fill shape balances 2.3 rounds of 256-row tiles better (4.5 rounds of its own)
         else if (v == 5 && g->in_dtype == 1 && g->act == 0 && g->out_dtype == 0) v = 11;
@@ -206,6 +217,11 @@ static int pick_variant(const MarsGemm* g) {
     }
     return v;
 }
+
+// Tuning hook: workgroups a persistent launch (variant 12) uses; 0 (default) = one per CU.  Fewer make every
+// workgroup walk more tiles (tests use that to reach the multi-tile path on small products).
+static std::atomic<int> g_gemm_slots{0};
+extern "C" int marship_set_gemm_slots(int slots) { return g_gemm_slots.exchange(slots > 0 ? slots : 0, std::memory_order_relaxed); }
 
 static int cu_count() {
     static std::atomic<int> cached{0};
@@ -228,7 +244,7 @@ static int cu_count() {
 // of their own, which the policy then gives a smaller tile.  (The same cut on the two-per-CU shapes was slower:
 // 256 x 128 137 -> 149 us, the projection on 128 x 128 with its 4.5 rounds 136 -> 145 us.)
 static int split_rows(const MarsGemm* g, int v) {
-    if (!g_gemm_split.load(std::memory_order_relaxed) || g_gemm_variant.load(std::memory_order_relaxed) != 4 || g->nb0 * g->nb1 != 1 || v != 8) return g->M;
+    if (!g_gemm_split.load(std::memory_order_relaxed) || g_gemm_variant.load(std::memory_order_relaxed) != 4 || g->nb0 * g->nb1 != 1 || (v != 8 && v != 12)) return g->M;
     const int slots = cu_count();
     const int64_t ntm = (g->M + 255) / 256, ntn = (g->N + 255) / 256, tiles = ntm * ntn;
     const int64_t full = tiles / slots, rem = tiles % slots;
@@ -288,6 +304,8 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
     if (g_gemm_variant.load(std::memory_order_relaxed) != 0) {
         const int v = pick_variant(g);
         const int rows = split_rows(g, v);
+        const int forced = g_gemm_slots.load(std::memory_order_relaxed);
+        const int slots = forced > 0 ? forced : cu_count();
         if (rows < g->M) {
             // rows [0, rows) fill whole rounds of tiles; the rest is a product of its own
             MarsGemm head = *g, tail = *g;
@@ -300,14 +318,14 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
             if (g->ln_lo) tail.ln_lo = (char*)g->ln_lo + (int64_t)rows * g->ldcopy * 2;
             if (g->ln_part) tail.ln_part = g->ln_part + (int64_t)rows * (g->N / 64) * 2;
             if (g->ln_stat) tail.ln_stat = g->ln_stat + (int64_t)rows * 2;
-            mars_gemm_ring_launch(head, s, v - 4);
+            mars_gemm_ring_launch(head, s, v - 4, slots);
             MARS_LAUNCH_CHECK();
             const int vt = pick_variant(&tail);
-            mars_gemm_ring_launch(tail, s, vt - 4);
+            mars_gemm_ring_launch(tail, s, vt - 4, slots);
             MARS_LAUNCH_CHECK();
             return 0;
         }
-        if (v == 3 || v >= 5) mars_gemm_ring_launch(*g, s, v == 3 ? 0 : v - 4);
+        if (v == 3 || v >= 5) mars_gemm_ring_launch(*g, s, v == 3 ? 0 : v - 4, slots);
         else mars_gemm_glds_launch(*g, s, v);
         MARS_LAUNCH_CHECK();
         return 0;

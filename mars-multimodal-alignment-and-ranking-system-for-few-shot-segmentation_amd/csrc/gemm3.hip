@@ -56,6 +56,7 @@ namespace {
 
 constexpr int STEP_B = 64;                               // bytes of K per row and step
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -119,9 +120,16 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& fa, const uint
 // CU's vector cache instead of fetching it from L2 again one step later, when it has long been evicted.  The
 // ring then has an even number of slots, filled a pair at a time at the top of every odd step (the pair of slots
 // steps 2p, 2p+1 used is free once the fragments of step 2p+1 are in registers), and one barrier per pair.
-template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE, int RING, bool PAIR = false>
+//
+// PERSIST: the launch has one workgroup per CU slot and each walks the tiles b, b + gridDim.x, ... of the
+// dispatch order (the tile -> XCD map stays what a launch of one workgroup per tile gives).  When the main loop
+// of a tile is done the ring is free, so the first RING steps of the NEXT tile are requested before the
+// accumulators are stored: the fill of the ring (a quarter of a tile's operand bytes at K = 1024) lands under
+// the store-bound epilogue instead of in front of an idle matrix pipe.
+template <typename TIN, typename TOUT, int NWR, int NWC, int FM, int FN, int WPE, int RING, bool PAIR = false, bool PERSIST = false>
 __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsGemm g, int group_m) {
     static_assert(!PAIR || (RING % 2 == 0 && RING >= 4 && RING <= 8), "pair fills need a ring of four, six or eight slots");
+    static_assert(!PERSIST || PAIR, "the persistent form is built on the pair-fill ring");
     constexpr int BM = 16 * FM * NWR, WN = 16 * FN, BN = WN * NWC, NWAVES = NWR * NWC;
     constexpr int A_BYTES = BM * STEP_B, B_BYTES = BN * STEP_B, STAGE = A_BYTES + B_BYTES;
     static_assert((BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0, "DMA pieces must divide among the waves");
@@ -136,21 +144,26 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     const int wr = wave / NWC, wc = wave % NWC;
     const int r16 = lane & 15, kq = lane >> 4;
     MARS_STAMP_ID()
-    MARS_STAMP(0)
 
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
     const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
-    {   // blocks that share an L2 (same blockIdx % 8) walk a contiguous range of tiles ...
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // ... in a grouped raster, so the 32 tiles an XCD has in flight form a compact patch
-    const int gsize = group_m * ntn;
-    const int first_m = (bid / gsize) * group_m;
-    const int gm = min(ntm - first_m, group_m);
-    const int tm = first_m + (bid % gsize) % gm, tn = (bid % gsize) / gm;
-    const int row0 = tm * BM, col0 = tn * BN;
+    // tile of dispatch slot `bid` (the blockIdx.x of a launch with one workgroup per tile)
+    auto locate = [&](int bid, int& r0, int& c0) {
+        {   // blocks that share an L2 (same blockIdx % 8) walk a contiguous range of tiles ...
+            const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        // ... in a grouped raster, so the 32 tiles an XCD has in flight form a compact patch
+        const int gsize = group_m * ntn;
+        const int first_m = (bid / gsize) * group_m;
+        const int gm = min(ntm - first_m, group_m);
+        const int tm = first_m + (bid % gsize) % gm, tn = (bid % gsize) / gm;
+        r0 = tm * BM;
+        c0 = tn * BN;
+    };
+    int vb = blockIdx.x;                                   // dispatch slot of the tile in hand
+    int row0, col0;
+    locate(vb, row0, col0);
     const int z = blockIdx.y, z0 = z / g.nb1, z1 = z % g.nb1;
     const unsigned char* Ab = (const unsigned char*)g.A + (z0 * g.sA0 + z1 * g.sA1) * (int64_t)sizeof(TIN);
     const unsigned char* Bb = (const unsigned char*)g.B + (z0 * g.sB0 + z1 * g.sB1) * (int64_t)sizeof(TIN);
@@ -159,20 +172,21 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     // DMA sources: piece i of this wave fills rows (i*NWAVES + wave)*16 .. +15 of A (then of B)
     const unsigned char* pa[A_PIECES];
     const unsigned char* pb[B_PIECES];
-    {
+    auto set_sources = [&](int r0, int c0) {
         const int lr = lane >> 2, ls = lane & 3;
         const int chunk = ls ^ gsw((lr >> 2) & 3);
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-            int ga = row0 + (i * NWAVES + wave) * 16 + lr; ga = ga < g.M ? ga : g.M - 1;
+            int ga = r0 + (i * NWAVES + wave) * 16 + lr; ga = ga < g.M ? ga : g.M - 1;
             pa[i] = Ab + ga * lda_b + (chunk << 4);
         }
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i) {
-            int gb = col0 + (i * NWAVES + wave) * 16 + lr; gb = gb < g.N ? gb : g.N - 1;
+            int gb = c0 + (i * NWAVES + wave) * 16 + lr; gb = gb < g.N ? gb : g.N - 1;
             pb[i] = Bb + gb * ldb_b + (chunk << 4);
         }
-    }
+    };
+    set_sources(row0, col0);
     // piece p of this wave's share of step s (A pieces first), into ring slot `slot`
     auto issue_piece = [&](int s, int slot, auto p_tag) {
         constexpr int p = decltype(p_tag)::value;
@@ -213,10 +227,6 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     };
 
     f32x4 acc[FM][FN];
-#pragma unroll
-    for (int m = 0; m < FM; ++m)
-#pragma unroll
-        for (int n = 0; n < FN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ns = (int)(((int64_t)g.K * sizeof(TIN)) / STEP_B);
     // The MFMAs compute C^T fragments (B rows are the first operand), so a lane ends up with four
@@ -320,15 +330,39 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         slot = nslot;                                                                                 \
     }
 
-    if constexpr (PAIR) {                                  // ns is even: K spans a multiple of 128 bytes
+    // the first RING steps of the tile whose sources are set, into slots 0 .. RING - 1
+    auto fill_ring = [&]() {
+        if constexpr (PAIR) {                              // ns is even: K spans a multiple of 128 bytes
 #pragma unroll
-        for (int i = 0; i < RING; i += 2)
-            if (i < ns) issue_pair(i, i, i + 1);
+            for (int i = 0; i < RING; i += 2)
+                if (i < ns) issue_pair(i, i, i + 1);
+        } else {
+#pragma unroll
+            for (int i = 0; i < RING; ++i)
+                if (i < ns) issue(i, i);
+        }
+    };
+    fill_ring();
+    int after_fill = 0;
+    bool warm = false;           // PERSIST: this tile's ring fill went out under the epilogue of the one before
+    for (;;) {                   // the tiles of this workgroup (one unless PERSIST)
+    MARS_STAMP(0)
+#pragma unroll
+    for (int m = 0; m < FM; ++m)
+#pragma unroll
+        for (int n = 0; n < FN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (PERSIST && warm) {
+        // the fill is older than everything the epilogue issued behind it, and vector memory operations retire
+        // in order: at most `after_fill` outstanding means the ring is filled
+        if (after_fill == 6) MARS_WAIT_VM(6);
+        else if (after_fill == 12) MARS_WAIT_VM(12);
+        else if (after_fill == 15) MARS_WAIT_VM(15);
+        else if (after_fill == 16) MARS_WAIT_VM(16);
+        else if (after_fill == 32) MARS_WAIT_VM(32);
+        else MARS_WAIT_VM(0);
+    } else if constexpr (PAIR) {
         wait_pairs(min(RING, ns) / 2 - 1);
     } else {
-#pragma unroll
-        for (int i = 0; i < RING; ++i)
-            if (i < ns) issue(i, i);
         if (ns >= RING) MARS_WAIT_VM((RING - 1) * PIECES);
         else MARS_WAIT_VM(0);
     }
@@ -343,13 +377,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         MARS_PHASE(faA, fbA, faB, fbB, s, false)
         if (s + 1 < ns) MARS_PHASE(faB, fbB, faA, fbA, s + 1, true)
     }
-#undef MARS_PHASE
-#undef MARS_WAIT_VM
     MARS_STAMP(2)
-    // every wave is past its last fragment read before the ring is reused for the epilogue
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    MARS_STAMP(3)
 
     // ---------------- epilogue ----------------
     // Wave tiles inside the matrix with 16-byte aligned rows store straight from the accumulators
@@ -359,12 +387,82 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     constexpr bool FAST = sizeof(TIN) == 2;
     constexpr int NV = PERM ? FN / 2 : FN, VW = PERM ? 8 : 4;     // 16-byte stores per fragment row, columns per store
     constexpr int VS = WN / NV;                                    // column distance between a lane's stores
+    // the shapes that keep three or four waves on a SIMD have no registers to spare for the folded LayerNorm forms
+    constexpr bool LN_OUT = FAST && sizeof(TOUT) == 4 && WPE <= 2, LN_IN = FAST && sizeof(TOUT) == 2 && WPE <= 2;
     TOUT* Cb = (TOUT*)g.C + (z0 * g.sC0 + z1 * g.sC1);
     const float* Rb = g.residual ? g.residual + (z0 * g.sR0 + z1 * g.sR1) : nullptr;
     const int wrow0 = row0 + wr * (16 * FM), wcol0 = col0 + wc * WN;
-    const bool inside = wcol0 + WN <= g.N;       // rows beyond M are masked per lane in the fast variants
+    // rows beyond M are masked per lane in the fast variants.  A persistent workgroup decides for the whole
+    // tile: the staged path writes to the ring, so no wave may be filling it for the next tile meanwhile
+    const bool inside = PERSIST ? col0 + BN <= g.N : wcol0 + WN <= g.N;
     const bool aligned = (g.ldc % (16 / (int)sizeof(TOUT)) == 0) && (((uintptr_t)Cb) % 16 == 0) &&
                          (!Rb || ((g.ldr % 4 == 0) && (((uintptr_t)Rb) % 16 == 0)));
+    // The per-column parameters of the register epilogues (and the row statistics of a folded LayerNorm) are
+    // requested here, in front of the barrier that ends the main loop, into the registers the operand
+    // fragments have left: their latency (a first touch of these lines per tile) passes while the workgroup
+    // gathers, not in front of the first store.
+    const int lcol = wcol0 + VW * kq;                      // store v of a row starts at lcol + v * VS
+    float bias_[NV][VW], gam_[NV][VW], csum_[LN_IN ? NV : 1][VW];
+    float mean_[LN_IN ? FM : 1], rstd_[LN_IN ? FM : 1];
+    {
+        const bool vec = (((uintptr_t)g.bias | (uintptr_t)g.gamma | (uintptr_t)g.ln_colsum) & 15) == 0;
+        auto cols = [&](const float* p, float def, auto& dst, int nv) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v >= nv) break;
+#pragma unroll
+                for (int q = 0; q < VW / 4; ++q) {
+                    f32x4 t = {def, def, def, def};
+                    if (p && inside) {
+                        const float* src = p + lcol + v * VS + 4 * q;
+                        if (vec) t = *(const f32x4*)src;
+                        else t = (f32x4){src[0], src[1], src[2], src[3]};
+                    }
+                    dst[v][4 * q] = t[0]; dst[v][4 * q + 1] = t[1]; dst[v][4 * q + 2] = t[2]; dst[v][4 * q + 3] = t[3];
+                }
+            }
+        };
+        cols(g.bias, 0.f, bias_, NV);
+        cols(g.gamma, 1.f, gam_, NV);
+        if constexpr (LN_IN) {
+            cols(g.ln_colsum, 0.f, csum_, NV);
+            if (g.ln_stat) {
+#pragma unroll
+                for (int m = 0; m < FM; ++m) {
+                    const int row = min(wrow0 + r16 + 16 * m, g.M - 1);
+                    const float2 st = *(const float2*)(g.ln_stat + 2 * (int64_t)row);
+                    mean_[m] = st.x;
+                    rstd_[m] = st.y;
+                }
+            }
+        }
+    }
+    // every wave is past its last fragment read before the ring is reused for the epilogue
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    MARS_STAMP(3)
+    // PERSIST: locate the next tile of this workgroup and request its first RING steps.  Called by the register
+    // epilogues behind their last load (a load issued behind the fill would wait for the whole fill to land)
+    // and in front of their stores; by the staged epilogue when it is done with the ring.
+    const bool has_next = PERSIST && vb + (int)gridDim.x < nwg;
+    int nrow0 = row0, ncol0 = col0;
+    // vector memory instructions this wave issues behind the fill (they retire behind it, in order), when the
+    // epilogue knows the number: the next tile then waits for the fill alone, not for the stores; 0 = unknown
+    after_fill = 0;
+    auto prefetch_next = [&]() {
+        if constexpr (PERSIST) {
+            if (has_next) {
+                // nothing of the epilogue may move up across the fill (it would be counted behind it)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                locate(vb + (int)gridDim.x, nrow0, ncol0);
+                set_sources(nrow0, ncol0);
+                fill_ring();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
 
     auto fast = [&](auto mode_tag, auto ln_tag) {
         constexpr int MODE = decltype(mode_tag)::value;    // 0 plain, 1 QuickGELU, 2 residual add, 3 erf GELU, 4 ReLU
@@ -376,27 +474,6 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         constexpr int LN = decltype(ln_tag)::value;
         constexpr bool PLANES = LN == 1 || LN == 3;
         static_assert(LN == 0 || (PLANES && MODE == 2 && sizeof(TOUT) == 4 && VW == 8) || (LN == 2 && MODE <= 1 && sizeof(TOUT) == 2));
-        const int lcol = wcol0 + VW * kq;                  // store v of a row starts at lcol + v * VS
-        float bias_[NV][VW], gam_[NV][VW], csum_[LN == 2 ? NV : 1][VW];
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-#pragma unroll
-            for (int e = 0; e < VW; ++e) {
-                bias_[v][e] = g.bias ? g.bias[lcol + v * VS + e] : 0.f;
-                gam_[v][e] = g.gamma ? g.gamma[lcol + v * VS + e] : 1.f;
-                if constexpr (LN == 2) csum_[v][e] = g.ln_colsum[lcol + v * VS + e];
-            }
-        // mean and rstd of the rows this lane holds
-        float mean_[LN == 2 ? FM : 1], rstd_[LN == 2 ? FM : 1];
-        if constexpr (LN == 2) {
-#pragma unroll
-            for (int m = 0; m < FM; ++m) {
-                const int row = min(wrow0 + r16 + 16 * m, g.M - 1);
-                const float2 st = *(const float2*)(g.ln_stat + 2 * (int64_t)row);
-                mean_[m] = st.x;
-                rstd_[m] = st.y;
-            }
-        }
         // Lanes of a C^T fragment that follow one another hold different ROWS, so a 16-byte access per lane reaches
         // memory as 64 requests of 16 bytes; four consecutive lanes on 64 consecutive bytes of one row go out as one
         // request and move 1.5-1.8 times the bytes per cycle (tools/diag_store.hip).  The residual is therefore
@@ -425,6 +502,13 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         __bf16* lp = PLANES ? (__bf16*)g.ln_lo + (int64_t)(wrow0 + r16s) * g.ldcopy + lcol_s : nullptr;
         const int rows_left = g.M - (wrow0 + r16);         // fragment row m of this lane exists iff 16 m < rows_left
         const int rows_left_s = g.M - (wrow0 + r16s);      // the same for the row this lane loads and stores
+        // every fragment row of this wave exists: the stores below are all issued
+        const bool whole = wrow0 + 16 * FM <= g.M;
+        constexpr int ST_ROW = LN == 1 ? 2 * NV + 1 : NV * (sizeof(TOUT) == 4 ? VW / 4 : 1);   // stores per fragment row
+        if constexpr (MODE != 2) {
+            prefetch_next();
+            if (whole) after_fill = FM * ST_ROW;
+        }
         auto load_res = [&](int m) {
             if (16 * m < rows_left_s) {
 #pragma unroll
@@ -448,6 +532,10 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
         for (int m = 0; m < FM; ++m) {
             if constexpr (MODE == 2) {
                 if (m + PD - 1 < FM) load_res(m + PD - 1);
+                if (m == (FM > PD ? FM - PD : 0)) {                     // the last residual row is on its way
+                    prefetch_next();
+                    if (whole) after_fill = (FM - m) * ST_ROW;
+                }
             }
             float rs = 0.f, rss = 0.f;                     // LN == 1: this lane's part of the row sums
 #pragma unroll
@@ -470,10 +558,28 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
                     const float a0 = PERM ? acc[m][2 * v + (e >> 2)][e & 3] : acc[m][v][e & 3];
-                    float y;
-                    if constexpr (LN == 2) y = fmaf(rstd_[m], fmaf(-mean_[m], csum_[v][e], a0), bias_[v][e]);
-                    else y = g.alpha * a0 + bias_[v][e];
-                    if constexpr (MODE == 1) y = act_fn3<FAST>(y, 2);
+                    if constexpr (LN == 2) x[e] = fmaf(rstd_[m], fmaf(-mean_[m], csum_[v][e], a0), bias_[v][e]);
+                    else x[e] = g.alpha * a0 + bias_[v][e];
+                }
+                if constexpr (MODE == 1 && FAST) {
+                    // QuickGELU two outputs at a time: the multiplies and the add around the two transcendentals
+                    // are packed instructions (act_fn3 per element leaves them single)
+#pragma unroll
+                    for (int e = 0; e < VW; e += 2) {
+                        const f32x2 y = {x[e], x[e + 1]};
+                        f32x2 t = y * (f32x2){-2.4554669595930157f, -2.4554669595930157f};
+                        t = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                        t = t + (f32x2){1.0f, 1.0f};
+                        t = (f32x2){__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+                        t = y * t;
+                        x[e] = t[0];
+                        x[e + 1] = t[1];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    float y = x[e];
+                    if constexpr (MODE == 1 && !FAST) y = act_fn3<FAST>(y, 2);
                     if constexpr (MODE == 3) y = act_fn3<FAST>(y, 1);
                     if constexpr (MODE == 4) y = fmaxf(y, 0.f);
                     y *= gam_[v][e];
@@ -532,8 +638,6 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
     using I2 = std::integral_constant<int, 2>;
     // the launcher admits the folded LayerNorm forms only for products every wave tile of which is inside and
     // aligned (N a multiple of 64), so they never reach the per-element path
-    // (the shapes that keep three or four waves on a SIMD have no registers to spare for them)
-    constexpr bool LN_OUT = FAST && sizeof(TOUT) == 4 && WPE <= 2, LN_IN = FAST && sizeof(TOUT) == 2 && WPE <= 2;
     const bool planes = LN_OUT && g.ln_lo != nullptr;
     if (inside && aligned && g.act == 0 && (Rb || planes)) {
         if constexpr (LN_OUT) {
@@ -590,18 +694,47 @@ __global__ __launch_bounds__(64 * NWR * NWC, WPE) void gemm_tn_ring_kernel(MarsG
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (half < 4) { MARS_STAMP(4 + half) }
         }
+        if constexpr (PERSIST) {
+            if (has_next) {
+                __builtin_amdgcn_s_barrier();              // every wave is done with its staging slab
+                asm volatile("" ::: "memory");
+                prefetch_next();
+            }
+        }
     }
 #ifdef MARS_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MARS_STAMP(8)
-    if (lane == 0) mars_stamp_buf[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+    if (!has_next) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MARS_STAMP(8)
+        if (lane == 0) mars_stamp_buf[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
+    if (!has_next) break;
+    vb += (int)gridDim.x;
+    row0 = nrow0;
+    col0 = ncol0;
+    warm = true;
+    }                            // tiles of this workgroup
+#undef MARS_PHASE
+#undef MARS_WAIT_VM
 }
 
 }  // namespace
 
 // M-tiles per raster group (tuning knob of the diagnostic tools)
 int mars_ring_group_m = 8;
+
+// one workgroup per CU slot (`slots`: CUs x workgroups a CU holds), each walking its share of the tiles; bf16
+// operands, unbatched.  A product with no more tiles than slots is the plain launch.
+template <int NWR, int NWC, int FM, int FN, int WPE, int RING>
+static void ring_launch_persistent(const MarsGemm& g, hipStream_t s, int slots) {
+    constexpr int BM = 16 * FM * NWR, BN = 16 * FN * NWC;
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    if (slots > 8) slots -= slots % 8;                     // a whole number of workgroups per XCD (locality only)
+    dim3 grid(tiles < slots || slots <= 0 ? tiles : slots, 1), block(64 * NWR * NWC);
+    if (g.out_dtype == 1) hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, __bf16, NWR, NWC, FM, FN, WPE, RING, true, true>), grid, block, 0, s, g, mars_ring_group_m);
+    else hipLaunchKernelGGL((gemm_tn_ring_kernel<__bf16, float, NWR, NWC, FM, FN, WPE, RING, true, true>), grid, block, 0, s, g, mars_ring_group_m);
+}
 
 template <int NWR, int NWC, int FM, int FN, int WPE, int RING, bool PAIR = false>
 static void ring_launch(const MarsGemm& g, hipStream_t s) {
@@ -619,8 +752,11 @@ static void ring_launch(const MarsGemm& g, hipStream_t s) {
 // shape 0: 256 x 256 tiles (8 waves, one workgroup per CU); 1: 256 x 128 (4 waves, two per CU);
 // 2: 128 x 128 (4 waves of 64 x 64, three per CU) for products with few tiles; 3: 64 x 128 (4 waves of
 // 32 x 64) for products that would not even give every CU a 128 x 128 tile
-void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape) {
-    if (shape == 0) ring_launch<2, 4, 8, 4, 2, 3>(g, s);
+// 8: the 256 x 256 pair-fill shape as persistent workgroups (bf16 operands, one batch entry; `slots` = CUs)
+void mars_gemm_ring_launch(const MarsGemm& g, hipStream_t s, int shape, int slots) {
+    if (shape == 8 && g.in_dtype == 1 && g.nb0 * g.nb1 == 1) ring_launch_persistent<2, 4, 8, 4, 2, 4>(g, s, slots);
+    else if (shape == 8) ring_launch<2, 4, 8, 4, 2, 4, true>(g, s);
+    else if (shape == 0) ring_launch<2, 4, 8, 4, 2, 3>(g, s);
     else if (shape == 1) ring_launch<2, 2, 8, 4, 2, 3>(g, s);
     else if (shape == 2) ring_launch<2, 2, 4, 4, 3, 3>(g, s);
     else if (shape == 3) ring_launch<2, 2, 2, 4, 4, 3>(g, s);

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "marship_set_gemm_variant": [_I],
     "marship_gemm_variant_for": [_P],
     "marship_set_gemm_split": [_I],
+    "marship_set_gemm_slots": [_I],
     "marship_gemm_split_rows": [_P],
     "marship_layernorm": [_P, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
     "marship_ln_finish": [_P, _I, _I, _I, _F, _P, _P],

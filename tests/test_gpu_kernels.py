@@ -45,7 +45,7 @@ def _act(z, act):
     return F.gelu(z) if act == 1 else (z * torch.sigmoid(1.702 * z) if act == 2 else (F.relu(z) if act == 3 else z))
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8, 11])
+@pytest.mark.parametrize("variant", [5, 6, 7, 8, 11, 12])
 @pytest.mark.parametrize("act", [1, 3])
 def test_gemm_fast_epilogue_activations(pkg, cuda, variant, act):
     """erf-GELU and ReLU on the register-direct epilogue of the ring kernels (aligned rows, no residual)."""
@@ -81,7 +81,7 @@ def test_gemm_epilogue(pkg, cuda, act):
     assert float((outb.float() - z).abs().max()) < 0.05
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (513, 257, 64), (256, 512, 1024), (70, 1100, 320)])
 def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):
@@ -110,6 +110,98 @@ def test_gemm_every_variant(pkg, cuda, variant, dtype, M, N, K):
         assert float((wide[:, N:] + 7.0).abs().max()) == 0.0
     finally:
         lib.marship_set_gemm_variant(old)
+
+
+@pytest.mark.parametrize("slots", [1, 3, 8, 24])
+def test_gemm_persistent_workgroups(pkg, cuda, slots):
+    """Variant 12 - workgroups that walk several tiles and request the next tile's first steps before they store
+    the one in hand - equals variant 8 (same tile, same summation order, one workgroup per tile) bit for bit:
+    register epilogues (plain, QuickGELU, f32 residual, folded-LayerNorm forms), the staged per-element epilogue
+    of a ragged product, and tiles with rows beyond M."""
+    lib, ops = pkg.hip.lib(), pkg.ops
+    bf = torch.bfloat16
+
+    def both(fn):
+        outs = []
+        for v in (8, 12):
+            old = lib.marship_set_gemm_variant(v)
+            old_slots = lib.marship_set_gemm_slots(slots)
+            try:
+                outs.append(fn())
+            finally:
+                lib.marship_set_gemm_variant(old)
+                lib.marship_set_gemm_slots(old_slots)
+        torch.cuda.synchronize()
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.equal(x, y)
+        return outs[0]
+
+    # aligned product, 5 x 6 tiles with a ragged last row tile
+    M, N, K = 1100, 1536, 512
+    a = _rand((M, K), 51, cuda).to(bf)
+    b = (_rand((N, K), 52, cuda) * 0.2).to(bf)
+    bias, gamma, res = _rand((N,), 53, cuda), _rand((N,), 54, cuda), _rand((M, N), 55, cuda)
+
+    def aligned():
+        o1 = torch.full((M, N), float("nan"), device=cuda, dtype=bf)
+        ops.linear(a, b, o1, bias=bias)
+        o2 = torch.full((M, N), float("nan"), device=cuda, dtype=bf)
+        ops.linear(a, b, o2, bias=bias, act=2, gamma=gamma)
+        o3 = res.clone()
+        ops.linear(a, b, o3, bias=bias, gamma=gamma, residual=o3)
+        o4 = torch.full((M, N), float("nan"), device=cuda)
+        ops.linear(a, b, o4)
+        return o1, o2, o3, o4
+
+    o1, o2, o3, o4 = both(aligned)
+    ref = a.double() @ b.double().t()
+    assert float((o4.double() - ref).abs().max()) < 2e-3
+    assert float((o3.double() - (res.double() + gamma.double() * (ref + bias.double()))).abs().max()) < 2e-3
+    y1 = ref + bias.double()
+    assert float(((o1.double() - y1).abs() - 2.0 ** -8 * y1.abs()).max()) < 1e-2       # one bf16 rounding
+
+    # ragged product: N edge tiles and unaligned rows go through the staged epilogue, with an activation and a residual
+    M2, N2, K2 = 700, 1100, 320
+    a2 = _rand((M2, K2), 56, cuda).to(bf)
+    b2 = (_rand((N2, K2), 57, cuda) * 0.2).to(bf)
+    bias2, res2 = _rand((N2,), 58, cuda), _rand((M2, N2), 59, cuda)
+
+    def ragged():
+        o1 = res2.clone()
+        ops.linear(a2, b2, o1, bias=bias2, residual=o1, act=2, alpha=0.5)
+        wide = torch.full((M2, N2 + 3), -7.0, device=cuda)
+        ops.linear(a2, b2, wide[:, :N2])
+        return o1, wide
+
+    r1, wide = both(ragged)
+    z = 0.5 * (a2.double() @ b2.double().t()) + bias2.double()
+    assert float((r1.double() - (res2.double() + z * torch.sigmoid(1.702 * z))).abs().max()) < 2e-3
+    assert float((wide[:, N2:] + 7.0).abs().max()) == 0.0
+
+    # folded-LayerNorm forms: the stream product (planes in, planes and row sums out) and its consumer
+    M3, D, K3 = 1000, 512, 1024
+    x0 = _rand((M3, D), 60, cuda) * 0.7 + 0.3
+    h = _rand((M3, K3), 61, cuda).to(bf)
+    w2 = (_rand((D, K3), 62, cuda) * 0.05).to(bf)
+    b2_, ls = _rand((D,), 63, cuda), _rand((D,), 64, cuda) * 0.5 + 1.0
+    wf = (_rand((1536, D), 65, cuda) * 0.05).to(bf)
+    colsum = wf.float().sum(1).contiguous()
+    bf_ = _rand((1536,), 66, cuda) * 0.1
+
+    def folded():
+        hi = torch.empty(M3, D, device=cuda, dtype=bf)
+        lo = torch.empty(M3, D, device=cuda, dtype=bf)
+        stat = torch.empty(M3, 2, device=cuda)
+        ops.row_stats(x0, 1e-5, hi, lo, stat)
+        part = torch.full((M3, D // 64, 2), float("nan"), device=cuda)
+        dummy = torch.zeros(M3, D, device=cuda)
+        ops.linear(h, w2, dummy, bias=b2_, gamma=ls, ln_out=(hi, lo, part))
+        ops.ln_finish(part, M3, D, 1e-5, stat)
+        out = torch.full((M3, 1536), float("nan"), device=cuda, dtype=bf)
+        ops.linear(hi, wf, out, bias=bf_, act=2, ln_in=(stat, colsum))
+        return hi, lo, part, stat, out
+
+    both(folded)
 
 
 def test_gemm_split_launch(pkg, cuda):

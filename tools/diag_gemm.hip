@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     if (argc > 7) mars_ring_group_m = atoi(argv[7]);
     // 5 / 7: 128x128 with pair fills (eight / four slots), 6: 64x128 with pair fills
     const int BMt = (shape == 2 || shape == 5 || shape == 7) ? 128 : (shape == 3 || shape == 6) ? 64 : 256;
-    const int BN = (shape == 0 || shape == 4) ? 256 : 128, NW = (shape == 0 || shape == 4) ? 8 : 4;
+    const int BN = (shape == 0 || shape == 4 || shape == 8) ? 256 : 128, NW = (shape == 0 || shape == 4 || shape == 8) ? 8 : 4;
     std::vector<unsigned short> ha((size_t)M * K), hb((size_t)N * K);
     unsigned x = 12345u;
     for (auto& v : ha) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((x >> 9) & 0x3ffu) + ((x >> 3) & 0x8000u)); }
@@ -32,7 +32,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&B, hb.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&bias, N * 4));
     CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(C, 0, (size_t)M * N * 4)); CK(hipMemset(bias, 0, N * 4));
-    const int nblk = ((M + BMt - 1) / BMt) * ((N + BN - 1) / BN);
+    int nblk = ((M + BMt - 1) / BMt) * ((N + BN - 1) / BN);
+    const int ntiles = nblk;
+    if (shape == 8 && nblk > 256) nblk = 256;            // persistent workgroups: stamps of each workgroup's LAST tile
     unsigned long long* stamps; const size_t nst = (size_t)nblk * 8 * 16;
     CK(hipMalloc(&stamps, nst * 8)); CK(hipMemset(stamps, 0, nst * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(mars_stamp_buf), &stamps, sizeof(stamps)));
@@ -41,16 +43,16 @@ int main(int argc, char** argv) {
     g.in_dtype = 1; g.out_dtype = out_f32 ? 0 : 1; g.alpha = 1.f; g.bias = bias; g.act = out_f32 ? 0 : 2;
     if (resid) { g.residual = (const float*)C; g.ldr = N; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) mars_gemm_ring_launch(g, 0, shape);
+    for (int i = 0; i < 20; ++i) mars_gemm_ring_launch(g, 0, shape, 256);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    mars_gemm_ring_launch(g, 0, shape);
+    mars_gemm_ring_launch(g, 0, shape, 256);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h(nst);
     CK(hipMemcpy(h.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
-    printf("M=%d N=%d K=%d shape=%d f32=%d res=%d: %.1f us, %d blocks\n", M, N, K, shape, out_f32, resid, ms * 1e3, nblk);
+    printf("M=%d N=%d K=%d shape=%d f32=%d res=%d: %.1f us, %d blocks, %d tiles\n", M, N, K, shape, out_f32, resid, ms * 1e3, nblk, ntiles);
     const char* names[9] = {"entry", "prologue", "mainloop", "ringfree", "slab0", "slab1", "slab2", "slab3", "retired"};
     for (int i = 1; i <= 8; ++i) {
         std::vector<double> d;
