@@ -34,7 +34,8 @@ class MARS:
         self._tables: Dict = {}
         self.vva = None
         self.vta = None
-        self.overlap = os.environ.get("MARS_OVERLAP", "0") == "1"
+        # start the proposal batch right behind the visual-visual tower (MARS_EARLY_BATCH=0: in the reference's order)
+        self.early_batch = os.environ.get("MARS_EARLY_BATCH", "1") != "0"
 
     def _nearest_table(self, n_in: int, n_out: int, device):
         """F.interpolate(mode='nearest') source indices: floor(dst * in/out) in float32 (line 77-81)."""
@@ -67,19 +68,23 @@ class MARS:
             support_images=support_images, support_masks=support_masks)
         self.time_start_ranking_after_text_extraction = time.time()
 
-        # lines 85-89; the AlphaCLIP batch needs nothing from the alignment towers, so with MARS_OVERLAP=1 it
-        # is queued first, on a stream of its own, and the towers run beside it.  Off by default: at 64
-        # proposals the batch already fills the chip and sharing it cost 6 % (52.9 against 49.9 ms a query).
-        # Giving the towers a CU range of their own (a stream with a CU mask, 24-64 of the 256 CUs) was worse
-        # still, 90-109 ms: their products fill most of the chip one tile per CU, so on a fifth of the CUs
-        # they take five times as long and the batch waits for them.
+        # lines 85-89.  The proposal stage needs the priors only for its last kernels: its pooling, its AlphaCLIP
+        # batch and its transport problems depend on the query, the proposals and the similarity matrix alone,
+        # so they are started right behind the visual-visual tower, on the same stream.  The GPU then has the
+        # long batch queued while the host issues the several hundred small launches of the text-alignment
+        # tower and of the prompt encoders (which the host cannot issue as fast as the GPU runs them), and the
+        # host solver starts 8-10 ms earlier.  Same kernels on the same inputs: results do not change.
+        # (The batch on a stream of its own BESIDE the towers was 6 % slower, and worse on a CU range of its
+        # own: at 64 proposals it fills the chip.  The text-alignment tower and the prompt encoders on a side
+        # stream beside the batch: 39.8 against 39.4 ms, their launches wait behind the batch's kernels.)
         text_alpha_clip = [f"a {name}."] if description == "" else [f"a {name}, {description}."]
         fmm = self.filtering_merging_component
-        if self.overlap and hasattr(fmm, "prefetch"):
-            fmm.prefetch(query_image, mask_proposals, text_alpha_clip)
-
         vva_mod = self.visual_visual_alignment_component
         vva = vva_mod.compute(support_imgs=support_images, support_masks=support_masks, query_img=query_image)
+        handle = vva_mod.similarity_handle() if hasattr(vva_mod, "similarity_handle") else None
+        if self.early_batch and hasattr(fmm, "begin"):
+            fmm.begin(query_image, mask_proposals, support_masks, handle if handle is not None else vva_mod.cost_matrix,
+                      vva_mod.model_embedding_spatial_dimensions)
         vta = self.visual_text_alignment_component.compute(query_image=query_image, fg_label=name, bg_labels=[])
 
         # lines 77-82: nearest resize of the text prior onto the visual grid, then min-max
@@ -93,7 +98,6 @@ class MARS:
         ops.minmax(vta_g.view(-1), vta_g.view(-1))
         self.vva, self.vta = vva.clone(), vta_g
 
-        handle = vva_mod.similarity_handle() if hasattr(vva_mod, "similarity_handle") else None
         predicted_mask = self.filtering_merging_component.compute(
             query_img=query_image, mask_proposals=mask_proposals, support_mask=support_masks,
             cost_matrix=handle if handle is not None else vva_mod.cost_matrix,

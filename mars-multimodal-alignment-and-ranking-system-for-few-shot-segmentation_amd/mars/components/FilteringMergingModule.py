@@ -8,10 +8,18 @@ Data flow per query: proposals are read once by the pooling kernel (patch occupa
 once by the alpha-plane resampler; the N AlphaCLIP passes run as one batch while the host
 solves the N transport problems; a single-block kernel combines the four scores in float64,
 ranks them and decides the kept set; the merge kernel ORs the kept proposals.
+
+Order of work: everything that needs neither prior (pooling, the AlphaCLIP batch, the transport
+problems) can be started with ``begin`` as soon as the similarity matrix is on its way - ``MARS.predict``
+does so right behind the visual-visual tower - so that the long GPU-bound batch is already queued while the
+host issues the many small launches of the text tower and of the prompt encoders, and the transport solver
+(a host thread of its own) has the whole batch to hide behind.  ``compute`` picks the started work up, or
+starts it itself when nobody did.
 """
 from __future__ import annotations
 
 import os
+import threading
 from typing import Callable, Dict, List, Optional, Union
 
 import torch
@@ -54,8 +62,7 @@ class FilteringMergingModule:
         self._tables: Dict = {}
         self._ws: Dict = {}
         self.last = {}
-        self._side: Optional[torch.cuda.Stream] = None
-        self._prefetched: Optional[dict] = None
+        self._begun: Optional[dict] = None
 
     # ---------------------------------------------------------------- tables / buffers
     def _aa_table(self, n_in, n_out):
@@ -87,6 +94,7 @@ class FilteringMergingModule:
                 cnt=torch.zeros(N, dtype=torch.int32, device=dev), ucnt=torch.zeros(1, dtype=torch.int32, device=dev),
                 svv=f(N), svt=f(N), aclip=f(N),
                 emd=torch.zeros(N, dtype=torch.float64, device=dev),
+                emd_host=torch.zeros(N, dtype=torch.float64).pin_memory(),
                 score=torch.zeros(N, dtype=torch.float64, device=dev),
                 order=torch.zeros(N, dtype=torch.int32, device=dev),
                 keep=torch.zeros(N, dtype=torch.uint8, device=dev),
@@ -107,24 +115,49 @@ class FilteringMergingModule:
                               vva, vta, text)
         return self._merge_masks(mask_proposals)
 
-    def prefetch(self, query_img, mask_proposals, text: List[str]):
-        """Queues the AlphaCLIP text / visual features on a side stream.  They depend only on the query
-        image, the proposals and the prompt, so the caller can start them before the two alignment towers
-        run: their many small launches then fill the CUs the big batch leaves idle at its tile tails.
-        ``_score_proposals`` picks the result up when it is handed the same proposals and prompt."""
+    def begin(self, query_img, mask_proposals, support_mask, cost_matrix, patch_features_spatial_dimension: int):
+        """Starts the part of ``compute`` that needs neither prior, on the current stream: patch occupancy of
+        the support masks and of the proposals with their copies to the host, the AlphaCLIP batch over the
+        proposals, and - on a host thread of its own - the transport problems, which start as soon as the
+        occupancy bits and the similarity matrix have reached the host.  ``compute`` with the same proposals
+        takes the result; anything else discards it."""
         dev = self.device
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(dev)
+        if self._begun is not None:             # started and never taken: its solver still reads the pinned buffers
+            self._begun["thread"].join()
+            self._begun = None
         masks = mask_proposals.to(dev).contiguous().float()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            tfeat = self._compute_alphaclip_text_feats(text)
-            feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks)
-            done = torch.cuda.Event()
-            done.record(self._side)
-        self._prefetched = dict(key=(mask_proposals.data_ptr(), tuple(mask_proposals.shape), tuple(text)), masks=masks,
-                                tfeat=tfeat, feats=feats, done=done)
+        N, S, _ = masks.shape
+        P = patch_features_spatial_dimension * patch_features_spatial_dimension
+        smask = support_mask.to(dev)[0].contiguous().float()       # [ns, S, S]
+        R = smask.shape[0] * P
+        w = self._buffers(N, S, P, R)
+        # lines 73-81, 104-110: patch occupancy of the support masks and of every proposal
+        ops.pool_masks(smask, patch_features_spatial_dimension, w["sbits"])
+        ops.pool_masks(masks, patch_features_spatial_dimension, w["bits"])
+        w["bits_host"].copy_(w["bits"], non_blocking=True)
+        w["fg_host"].copy_(w["sbits"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        # lines 112-116, 142-169: the N transport problems, solved on host threads while the GPU runs the batch
+        job = dict(result=None, error=None)
+        if not isinstance(cost_matrix, SimilarityHandle):
+            cost_matrix = cost_matrix.detach().cpu().float().contiguous()
+
+        def solve():
+            try:
+                ev.synchronize()
+                job["result"] = self._compute_emd_scores(cost_matrix, w["fg_host"], w["bits_host"])
+            except BaseException as exc:        # handed to the caller of compute()
+                job["error"] = exc
+
+        thread = threading.Thread(target=solve, name="mars-emd", daemon=True)
+        thread.start()
+        # lines 183-207: the AlphaCLIP visual features of every proposal
+        feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w)
+        self._begun = dict(key=(mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(),
+                                patch_features_spatial_dimension),
+                           w=w, masks=masks, feats=feats, job=job, thread=thread, N=N, P=P)
+        return self._begun
 
     def _compute_alphaclip_text_feats(self, text: List[str]) -> torch.Tensor:
         """Lines 171-181 (normalisation happens inside the cosine-score kernel)."""
@@ -164,35 +197,26 @@ class FilteringMergingModule:
 
     def _score_proposals(self, query_img, mask_proposals, support_mask, cost_matrix, G: int, vva, vta, text):
         dev = self.device
-        masks = mask_proposals.to(dev).contiguous().float()
-        N, S, _ = masks.shape
-        P = G * G
-        smask = support_mask.to(dev)[0].contiguous().float()       # [ns, S, S]
-        R = smask.shape[0] * P
-        w = self._buffers(N, S, P, R)
-        # lines 73-81, 104-110: patch occupancy of the support masks and of every proposal
-        ops.pool_masks(smask, G, w["sbits"])
-        ops.pool_masks(masks, G, w["bits"])
-        w["bits_host"].copy_(w["bits"], non_blocking=True)
-        w["fg_host"].copy_(w["sbits"], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        st, self._begun = self._begun, None
+        if st is not None and st["key"] != (mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(), G):
+            st["thread"].join()                 # started for other inputs: let it finish, then start over
+            st = None
+        if st is None:
+            st = self.begin(query_img, mask_proposals, support_mask, cost_matrix, G)
+            self._begun = None
+        w, masks, N, P, feats = st["w"], st["masks"], st["N"], st["P"], st["feats"]
         ops.proposal_stats(w["bits"], N, P, vva.to(dev).contiguous().float().view(-1), vta.to(dev).contiguous().float().view(-1),
                            w["cnt"], w["svv"], w["svt"], w["ucnt"])
-        # lines 90-97: AlphaCLIP text/visual features and their cosine (queued on the GPU ...)
-        pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre["key"] == (mask_proposals.data_ptr(), tuple(mask_proposals.shape), tuple(text)):
-            tfeat, feats, joined = pre["tfeat"], pre["feats"], pre["done"]
-        else:
-            tfeat = self._compute_alphaclip_text_feats(text)
-            feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w)
-            joined = None
-        # lines 112-116, 142-169: ... while the host solves the N transport problems
-        ev.synchronize()
-        w["emd"].copy_(self._compute_emd_scores(cost_matrix, w["fg_host"], w["bits_host"]), non_blocking=False)
-        if joined is not None:
-            torch.cuda.current_stream(dev).wait_event(joined)
+        # lines 90-97: the AlphaCLIP text features and the cosines (queued behind the batch)
+        tfeat = self._compute_alphaclip_text_feats(text)
         ops.cosine_scores(feats, tfeat, w["aclip"])
+        # the transport scores: through pinned memory, so that the copy and everything behind it are queued
+        # while the batch is still running and the GPU goes from the batch to the ranking without the host
+        st["thread"].join()
+        if st["job"]["error"] is not None:
+            raise st["job"]["error"]
+        w["emd_host"].copy_(st["job"]["result"])
+        w["emd"].copy_(w["emd_host"], non_blocking=True)
         # lines 118-138, 213-217: combine, rank, keep
         ops.rank(w["emd"], w["aclip"], w["cnt"], w["svv"], w["svt"], w["ucnt"], N, self.alpha, self.static_threshold,
                  self.dynamic_threshold, w["score"], w["order"], w["keep"])

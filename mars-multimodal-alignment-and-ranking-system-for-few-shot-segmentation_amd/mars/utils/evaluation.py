@@ -24,4 +24,4 @@ class Evaluator:
         for b in range(B):
             ops.iou_counts(pred_mask[b].contiguous().float(), gt_mask[b].contiguous().float(),
                            ignore[b].contiguous().float() if ignore is not None else None, counts[b])
-        return counts[:, 0:2].t().contiguous(), counts[:, 2:4].t().contiguous()
+        return counts[:, 0:2].t(), counts[:, 2:4].t()          # views: [2, B] each

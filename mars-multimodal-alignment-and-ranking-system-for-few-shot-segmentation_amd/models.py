@@ -417,12 +417,12 @@ class _TextTower:
         """encode_text (clip/model.py:486-499): causal transformer, EOT feature, text_projection."""
         tokens_cpu = tokens.cpu()
         n, L = tokens_cpu.shape
-        idx = tokens_cpu.long().to(self.device)
+        idx = ops.upload_small(tokens_cpu.long(), self.device)      # queued, not waited for (ops._PinnedRing)
         X = (self.tok.index_select(0, idx.reshape(-1)).view(n, L, -1) + self.pos).contiguous()  # embedding gather
         for blk in self.tower.blocks:
             self.tower.block_forward(X, blk, causal=True)
         eot = tokens_cpu.argmax(dim=-1)
-        rows = (torch.arange(n) * L + eot).to(self.device)
+        rows = ops.upload_small(torch.arange(n) * L + eot, self.device)
         W = self.cfg.transformer_width
         sel = X.view(n * L, W).index_select(0, rows).contiguous()
         y = torch.empty(n, W, dtype=torch.float32, device=self.device)

@@ -46,6 +46,54 @@ def _req(cond: bool, msg: str):
         raise ValueError(msg)
 
 
+class _PinnedRing:
+    """Small host-to-device uploads that do not stall the host.  A copy from pageable memory waits until the
+    stream has run dry before it returns; from one of these pinned slots it is queued like a kernel.  A slot is
+    reused only after the copy that last read it has run (its event), which with ``slots`` uploads in flight
+    never blocks in practice."""
+
+    def __init__(self, device, slots: int = 16, nbytes: int = 1 << 14):
+        self.device, self.nbytes, self.i = device, nbytes, 0
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+
+    def upload(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        n = t.numel() * t.element_size()
+        out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+        if n == 0:
+            return out
+        if n > self.nbytes:                      # too large for a slot: the plain (blocking) copy
+            out.copy_(t)
+            return out
+        i, self.i = self.i, (self.i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        view = self.bufs[i][:n].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        out.copy_(view, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[i] = ev
+        return out
+
+
+_RINGS: dict = {}
+
+
+def upload_small(t: torch.Tensor, device) -> torch.Tensor:
+    """A CPU tensor of a few KiB (token ids, row indices) on ``device``, queued on the current stream
+    without waiting for the work already queued there.  Tensors already on the device are returned as they are."""
+    if t.is_cuda:
+        return t
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ring = _RINGS.get(key)
+    if ring is None:
+        ring = _RINGS[key] = _PinnedRing(device)
+    return ring.upload(t)
+
+
 def _dev(*ts):
     """Every operand must live on the GPU that is current: the kernels are launched on the current
     device's current stream, so an operand of another GPU would be reached across devices with no

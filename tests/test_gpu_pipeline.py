@@ -124,16 +124,17 @@ def test_reference_signature_with_explicit_cost_matrix(pkg, cuda):
     assert maxdiff(mars.filtering_merging_component.scores()["score"], s1) < 1e-12
 
 
-def test_side_stream_start_gives_the_same_result(pkg, cuda):
-    """MARS_OVERLAP: the AlphaCLIP batch queued on its own stream before the alignment towers."""
+def test_early_batch_start_gives_the_same_result(pkg, cuda):
+    """The proposal batch and the transport solver started right behind the visual-visual tower (the default)
+    against the reference's order of work (MARS_EARLY_BATCH=0)."""
     cfg = tiny_config(pkg)
     ep = pkg.synth.make_episode(9, size=cfg["size"], nshot=cfg["nshot"], nprop=cfg["nprop"])
     args = [ep[k].to(cuda) for k in ("support_imgs", "support_masks", "query_img", "mask_proposals")]
     out = {}
     for overlap in (False, True):
         mars = _build(pkg, cfg)
-        mars.overlap = overlap
-        for _ in range(2):                      # the second call reuses the side stream and its buffers
+        mars.early_batch = overlap
+        for _ in range(2):                      # the second call reuses the buffers of the first
             pred = mars.predict(*args)
         out[overlap] = (pred.clone(), {k: v.clone() for k, v in mars.filtering_merging_component.scores().items()})
     assert torch.equal(out[False][0], out[True][0])
