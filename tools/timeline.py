@@ -25,7 +25,8 @@ mars = MARS.build_MARS_fss(bench.build_args(dev, torch.bfloat16), state_dicts=sd
 Evaluator.initialize()
 meter = AverageMeter(types.SimpleNamespace(benchmark="coco", class_ids=[4 * i for i in range(20)]), device=dev)
 eps = []
-for e in range(6):
+NSTEPS = int(os.environ.get("STEPS", "4"))
+for e in range(2 + NSTEPS):
     ep = pkg.synth.make_episode(e, size=bench.SIZE, nshot=1, nprop=bench.NPROP, fold=0)
     eps.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in ep.items()})
 
@@ -84,14 +85,19 @@ def step(ep):
 for k in range(2):
     step(eps[k])
 torch.cuda.synchronize()
-for k in range(2, 6):
+for k in range(2, 2 + NSTEPS):
     marks.clear()
     t_prev = time.perf_counter()
     step(eps[k])
     torch.cuda.synchronize()
     t0 = marks[0][1]
     e0 = marks[0][2]
-    print(f"step {k}: wall {1e3 * (marks[-1][1] - t0):.2f} ms")
+    byl = {m[0]: m for m in marks}
+    emd_ms = 1e3 * (byl["emd solved"][1] - byl["emd begin (bits on host)"][1])
+    print(f"step {k}: wall {1e3 * (marks[-1][1] - t0):.2f} ms, emd {emd_ms:.1f} ms from {1e3 * (byl['emd begin (bits on host)'][1] - t0):.1f}, "
+          f"batch done on the gpu at {e0.elapsed_time(byl['alphaclip queued'][2]):.1f}")
+    if NSTEPS > 6:
+        continue
     for label, t, ev in sorted(marks, key=lambda m: m[1]):
         gpu = f"{e0.elapsed_time(ev):8.2f}" if ev is not None else "       -"
         print(f"   {label:28s} host {1e3 * (t - t0):8.2f} ms   gpu reaches it at {gpu} ms")
