@@ -151,3 +151,4 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().marship_last_error()
         raise MarsHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+

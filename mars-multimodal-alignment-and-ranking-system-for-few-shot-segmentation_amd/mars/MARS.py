@@ -36,6 +36,9 @@ class MARS:
         self.vta = None
         # start the proposal batch right behind the visual-visual tower (MARS_EARLY_BATCH=0: in the reference's order)
         self.early_batch = os.environ.get("MARS_EARLY_BATCH", "1") != "0"
+        # the three stages side by side on streams of their own (see _predict)
+        self.concurrent = os.environ.get("MARS_CONCURRENT", "1") != "0"
+        self._streams = None
 
     def _nearest_table(self, n_in: int, n_out: int, device):
         """F.interpolate(mode='nearest') source indices: floor(dst * in/out) in float32 (line 77-81)."""
@@ -68,47 +71,85 @@ class MARS:
             support_images=support_images, support_masks=support_masks)
         self.time_start_ranking_after_text_extraction = time.time()
 
-        # lines 85-89.  The proposal stage needs the priors only for its last kernels: its pooling, its AlphaCLIP
-        # batch and its transport problems depend on the query, the proposals and the similarity matrix alone,
-        # so they are started right behind the visual-visual tower, on the same stream.  The GPU then has the
-        # long batch queued while the host issues the several hundred small launches of the text-alignment
-        # tower and of the prompt encoders (which the host cannot issue as fast as the GPU runs them), and the
-        # host solver starts 8-10 ms earlier.  Same kernels on the same inputs: results do not change.
-        # (The batch on a stream of its own BESIDE the towers was 6 % slower, and worse on a CU range of its
-        # own: at 64 proposals it fills the chip.  The text-alignment tower and the prompt encoders on a side
-        # stream beside the batch: 39.8 against 39.4 ms, their launches wait behind the batch's kernels.)
+        # lines 85-89.  What depends on what: the visual prior and the similarity matrix need the visual-visual
+        # tower; the text prior needs the text-alignment tower and its prompt encoder; the proposal stage needs
+        # the priors only for its last kernels - its pooling, its AlphaCLIP batch and its transport problems
+        # depend on the query, the proposals and the similarity matrix alone.  The reference runs the three one
+        # after the other.  Here (``concurrent``, the default) they are queued side by side:
+        #   the visual-visual tower on a high-priority stream: the host solver waits for its similarity matrix;
+        #   the proposal batch, 3/4 of the work, on the caller's stream; it starts at once;
+        #   the text-alignment tower and the two prompt encoders on streams of their own: chains of several
+        #   hundred small launches that fill what the batch leaves free (its rounds' tails, the gaps between
+        #   its launches) instead of running alone on an idle chip behind it.
+        # Same kernels on the same inputs, so results do not change.  Measured (one process, interleaved, a step
+        # of the benchmark): everything on one stream 37.2-39.1 ms depending on the box, side by side 34.6-34.9;
+        # all streams at one priority 36.0; the small chains at LOW priority 38.7 (they starve until the batch
+        # ends); the batch at high priority and the visual-visual tower at normal 34.6-34.9 as well, but the
+        # solver then starts late.  ``concurrent = False`` (MARS_CONCURRENT=0) queues everything on the
+        # caller's stream, the batch right behind the visual-visual tower.
         text_alpha_clip = [f"a {name}."] if description == "" else [f"a {name}, {description}."]
         fmm = self.filtering_merging_component
         vva_mod = self.visual_visual_alignment_component
-        vva = vva_mod.compute(support_imgs=support_images, support_masks=support_masks, query_img=query_image)
-        handle = vva_mod.similarity_handle() if hasattr(vva_mod, "similarity_handle") else None
-        if self.early_batch and hasattr(fmm, "begin"):
-            fmm.begin(query_image, mask_proposals, support_masks, handle if handle is not None else vva_mod.cost_matrix,
-                      vva_mod.model_embedding_spatial_dimensions)
-        vta = self.visual_text_alignment_component.compute(query_image=query_image, fg_label=name, bg_labels=[])
+        vta_mod = self.visual_text_alignment_component
+        G = vva_mod.model_embedding_spatial_dimensions
+        dev = getattr(fmm, "device", None)
+        staged = hasattr(fmm, "begin") and hasattr(vta_mod, "prepare_text") and hasattr(fmm, "prepare_text")
+        if self.concurrent and staged and isinstance(dev, torch.device) and dev.type == "cuda":
+            main = torch.cuda.current_stream(dev)
+            st = self._get_streams(dev)
+            for s_ in st.values():
+                s_.wait_stream(main)
+            with torch.cuda.stream(st["high"]):
+                vva = vva_mod.compute(support_imgs=support_images, support_masks=support_masks, query_img=query_image)
+            handle = vva_mod.similarity_handle() if hasattr(vva_mod, "similarity_handle") else None
+            fmm.begin(query_image, mask_proposals, support_masks, None, G)
+            if handle is not None:
+                fmm.start_solver(handle)
+            vta_mod.prepare_text(name, st["text0"])
+            fmm.prepare_text(text_alpha_clip, st["text1"])
+            with torch.cuda.stream(st["vta"]):
+                vta = vta_mod.compute(query_image=query_image, fg_label=name, bg_labels=[])
+                vta_g = self._text_prior_on_visual_grid(vta, vva.shape[0], dev)
+            main.wait_stream(st["high"])
+            main.wait_stream(st["vta"])
+            if handle is None:
+                fmm.start_solver(vva_mod.cost_matrix)
+        else:
+            vva = vva_mod.compute(support_imgs=support_images, support_masks=support_masks, query_img=query_image)
+            handle = vva_mod.similarity_handle() if hasattr(vva_mod, "similarity_handle") else None
+            if self.early_batch and hasattr(fmm, "begin"):
+                fmm.begin(query_image, mask_proposals, support_masks, handle if handle is not None else vva_mod.cost_matrix, G)
+            vta = vta_mod.compute(query_image=query_image, fg_label=name, bg_labels=[])
+            vta_g = self._text_prior_on_visual_grid(vta, vva.shape[0], vva.device)
+        self.vva, self.vta = vva.clone(), vta_g
 
-        # lines 77-82: nearest resize of the text prior onto the visual grid, then min-max
-        G, Gv = vva.shape[0], vta.shape[0]
-        dev = vva.device
+        predicted_mask = self.filtering_merging_component.compute(
+            query_img=query_image, mask_proposals=mask_proposals, support_mask=support_masks,
+            cost_matrix=handle if handle is not None else vva_mod.cost_matrix,
+            patch_features_spatial_dimension=G, vva=vva, vta=vta_g, text=text_alpha_clip)
+        # the components write into buffers they reuse on the next call; the reference hands out fresh
+        # tensors (FilteringMergingModule.py:219), so the caller gets a copy that the next predict() leaves alone
+        predicted_mask = predicted_mask.clone()
+        torch.cuda.synchronize(vva.device)  # kernels are asynchronous: the end stamp must include them
+        self.time_end_ranking = time.time()
+        return predicted_mask
+
+    def _text_prior_on_visual_grid(self, vta, G, dev):
+        """Lines 77-82: nearest resize of the text prior onto the visual grid, then min-max."""
+        Gv = vta.shape[0]
         t = self._nearest_table(Gv, G, dev)
         tmp = torch.empty(Gv, G, dtype=torch.float32, device=dev)
         vta_g = torch.empty(G, G, dtype=torch.float32, device=dev)
         ops.resample_axis(vta.contiguous(), 1, Gv, Gv, 1, t, tmp)
         ops.resample_axis(tmp, 1, Gv, G, 0, t, vta_g)
         ops.minmax(vta_g.view(-1), vta_g.view(-1))
-        self.vva, self.vta = vva.clone(), vta_g
+        return vta_g
 
-        predicted_mask = self.filtering_merging_component.compute(
-            query_img=query_image, mask_proposals=mask_proposals, support_mask=support_masks,
-            cost_matrix=handle if handle is not None else vva_mod.cost_matrix,
-            patch_features_spatial_dimension=vva_mod.model_embedding_spatial_dimensions,
-            vva=vva, vta=vta_g, text=text_alpha_clip)
-        # the components write into buffers they reuse on the next call; the reference hands out fresh
-        # tensors (FilteringMergingModule.py:219), so the caller gets a copy that the next predict() leaves alone
-        predicted_mask = predicted_mask.clone()
-        torch.cuda.synchronize(dev)  # kernels are asynchronous: the end stamp must include them
-        self.time_end_ranking = time.time()
-        return predicted_mask
+    def _get_streams(self, dev):
+        if self._streams is None or self._streams["device"] != dev:
+            side = lambda: torch.cuda.Stream(device=dev)      # noqa: E731
+            self._streams = dict(device=dev, high=torch.cuda.Stream(device=dev, priority=-1), vta=side(), text0=side(), text1=side())
+        return {k: v for k, v in self._streams.items() if k != "device"}
 
     def clear(self):
         self.visual_visual_alignment_component.clear()

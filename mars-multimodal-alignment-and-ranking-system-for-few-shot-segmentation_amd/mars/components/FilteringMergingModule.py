@@ -123,7 +123,8 @@ class FilteringMergingModule:
         takes the result; anything else discards it."""
         dev = self.device
         if self._begun is not None:             # started and never taken: its solver still reads the pinned buffers
-            self._begun["thread"].join()
+            if self._begun["job"]["thread"] is not None:
+                self._begun["job"]["thread"].join()
             self._begun = None
         masks = mask_proposals.to(dev).contiguous().float()
         N, S, _ = masks.shape
@@ -138,26 +139,45 @@ class FilteringMergingModule:
         w["fg_host"].copy_(w["sbits"], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        # lines 112-116, 142-169: the N transport problems, solved on host threads while the GPU runs the batch
-        job = dict(result=None, error=None)
-        if not isinstance(cost_matrix, SimilarityHandle):
-            cost_matrix = cost_matrix.detach().cpu().float().contiguous()
-
-        def solve():
-            try:
-                ev.synchronize()
-                job["result"] = self._compute_emd_scores(cost_matrix, w["fg_host"], w["bits_host"])
-            except BaseException as exc:        # handed to the caller of compute()
-                job["error"] = exc
-
-        thread = threading.Thread(target=solve, name="mars-emd", daemon=True)
-        thread.start()
+        job = dict(result=None, error=None, thread=None, ready=ev, w=w)
+        if cost_matrix is not None:
+            self._start_solver(job, cost_matrix)
         # lines 183-207: the AlphaCLIP visual features of every proposal
         feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w)
         self._begun = dict(key=(mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(),
                                 patch_features_spatial_dimension),
-                           w=w, masks=masks, feats=feats, job=job, thread=thread, N=N, P=P)
+                           w=w, masks=masks, feats=feats, job=job, N=N, P=P)
         return self._begun
+
+    def start_solver(self, cost_matrix):
+        """The transport problems of the work ``begin`` started without a similarity matrix (``cost_matrix=None``)."""
+        if self._begun is not None and self._begun["job"]["thread"] is None:
+            self._start_solver(self._begun["job"], cost_matrix)
+
+    def _start_solver(self, job: dict, cost_matrix):
+        """Lines 112-116, 142-169: the N transport problems, on a host thread of its own (the solver's worker threads
+        hang below it) that first waits for the occupancy bits and the similarity matrix to reach the host."""
+        if not isinstance(cost_matrix, SimilarityHandle):
+            cost_matrix = cost_matrix.detach().cpu().float().contiguous()
+        w = job["w"]
+
+        def solve():
+            try:
+                job["ready"].synchronize()
+                job["result"] = self._compute_emd_scores(cost_matrix, w["fg_host"], w["bits_host"])
+            except BaseException as exc:        # handed to the caller of compute()
+                job["error"] = exc
+
+        job["thread"] = threading.Thread(target=solve, name="mars-emd", daemon=True)
+        job["thread"].start()
+
+    def prepare_text(self, text: List[str], stream: "torch.cuda.Stream"):
+        """Queues the AlphaCLIP prompt features on ``stream``; ``compute`` with the same prompt waits for them there."""
+        with torch.cuda.stream(stream):
+            tfeat = self._compute_alphaclip_text_feats(text)
+            done = torch.cuda.Event()
+            done.record(stream)
+        self._prepared_text = (tuple(text), tfeat, done)
 
     def _compute_alphaclip_text_feats(self, text: List[str]) -> torch.Tensor:
         """Lines 171-181 (normalisation happens inside the cosine-score kernel)."""
@@ -199,7 +219,8 @@ class FilteringMergingModule:
         dev = self.device
         st, self._begun = self._begun, None
         if st is not None and st["key"] != (mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(), G):
-            st["thread"].join()                 # started for other inputs: let it finish, then start over
+            if st["job"]["thread"] is not None:
+                st["job"]["thread"].join()      # started for other inputs: let it finish, then start over
             st = None
         if st is None:
             st = self.begin(query_img, mask_proposals, support_mask, cost_matrix, G)
@@ -208,11 +229,18 @@ class FilteringMergingModule:
         ops.proposal_stats(w["bits"], N, P, vva.to(dev).contiguous().float().view(-1), vta.to(dev).contiguous().float().view(-1),
                            w["cnt"], w["svv"], w["svt"], w["ucnt"])
         # lines 90-97: the AlphaCLIP text features and the cosines (queued behind the batch)
-        tfeat = self._compute_alphaclip_text_feats(text)
+        prepared = getattr(self, "_prepared_text", None)
+        if prepared is not None and prepared[0] == tuple(text):
+            tfeat = prepared[1]
+            torch.cuda.current_stream(dev).wait_event(prepared[2])
+        else:
+            tfeat = self._compute_alphaclip_text_feats(text)
         ops.cosine_scores(feats, tfeat, w["aclip"])
         # the transport scores: through pinned memory, so that the copy and everything behind it are queued
         # while the batch is still running and the GPU goes from the batch to the ranking without the host
-        st["thread"].join()
+        if st["job"]["thread"] is None:
+            self._start_solver(st["job"], cost_matrix)
+        st["job"]["thread"].join()
         if st["job"]["error"] is not None:
             raise st["job"]["error"]
         w["emd_host"].copy_(st["job"]["result"])

@@ -81,13 +81,27 @@ class VisualTextAlignmentModule:
         ops.l2norm_rows(a.view(1, n, E), 0, n, b)
         return b
 
+    def prepare_text(self, fg_label: str, stream: "torch.cuda.Stream"):
+        """Queues the prompt features of ``fg_label`` on ``stream`` (a chain of small launches that needs nothing
+        from the image tower and can run beside it); ``compute`` for the same label waits for them there."""
+        with torch.cuda.stream(stream):
+            text = self.compute_text_feats(fg_label)
+            done = torch.cuda.Event()
+            done.record(stream)
+        self._prepared = (fg_label, text, done)
+
     def compute(self, query_image: torch.Tensor, fg_label: str, bg_labels: List[str]) -> torch.Tensor:
         assert len(bg_labels) == 0, "the ranking path always calls with bg_labels=[] (mars/MARS.py:72)"
         image = self.preprocess(query_image[0].to(self.device))
         T = (image.shape[-1] // self.model_patch_size) ** 2 + 1
         acc = self.pir.new_accumulator(T - 1)
         X, _ = self.model.encode_image_tokens(image[None], self._mean, self._std, mean_attn=(acc, self.last_n))
-        text = self.compute_text_feats(fg_label)
+        prepared = getattr(self, "_prepared", None)
+        if prepared is not None and prepared[0] == fg_label:
+            text = prepared[1]
+            torch.cuda.current_stream(self.device).wait_event(prepared[2])
+        else:
+            text = self.compute_text_feats(fg_label)
         L, H = self.model.cfg.vision_layers, self.model.cfg.vision_heads
         last = (acc, 1, T - 1, 1.0 / (min(self.last_n, L) * H)) if self.last_n >= 1 else None
         cam, logits, _ = self.model.gradcam(X, text, mean_attn=last)

@@ -124,22 +124,27 @@ def test_reference_signature_with_explicit_cost_matrix(pkg, cuda):
     assert maxdiff(mars.filtering_merging_component.scores()["score"], s1) < 1e-12
 
 
-def test_early_batch_start_gives_the_same_result(pkg, cuda):
-    """The proposal batch and the transport solver started right behind the visual-visual tower (the default)
-    against the reference's order of work (MARS_EARLY_BATCH=0)."""
+def test_order_of_work_does_not_change_the_result(pkg, cuda):
+    """The reference's order of work (everything on one stream, stage after stage), the proposal batch and the
+    transport solver started right behind the visual-visual tower, and the default - the three stages side by
+    side on streams of their own - give the same prediction and the same scores, bit for bit."""
     cfg = tiny_config(pkg)
     ep = pkg.synth.make_episode(9, size=cfg["size"], nshot=cfg["nshot"], nprop=cfg["nprop"])
     args = [ep[k].to(cuda) for k in ("support_imgs", "support_masks", "query_img", "mask_proposals")]
     out = {}
-    for overlap in (False, True):
+    for mode in ("reference order", "early batch", "concurrent"):
         mars = _build(pkg, cfg)
-        mars.early_batch = overlap
-        for _ in range(2):                      # the second call reuses the buffers of the first
+        mars.concurrent = mode == "concurrent"
+        mars.early_batch = mode != "reference order"
+        for _ in range(3):                      # later calls reuse the streams and the buffers of the first
             pred = mars.predict(*args)
-        out[overlap] = (pred.clone(), {k: v.clone() for k, v in mars.filtering_merging_component.scores().items()})
-    assert torch.equal(out[False][0], out[True][0])
-    for k in ("emd", "aclip", "score", "order"):
-        assert torch.equal(out[False][1][k], out[True][1][k]), k
+        out[mode] = (pred.clone(), {k: v.clone() for k, v in mars.filtering_merging_component.scores().items()},
+                     mars.vva.clone(), mars.vta.clone())
+    for mode in ("early batch", "concurrent"):
+        assert torch.equal(out["reference order"][0], out[mode][0]), mode
+        for k in ("emd", "aclip", "score", "order"):
+            assert torch.equal(out["reference order"][1][k], out[mode][1][k]), (mode, k)
+        assert torch.equal(out["reference order"][2], out[mode][2]) and torch.equal(out["reference order"][3], out[mode][3]), mode
 
 
 two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
