@@ -21,6 +21,6 @@ for kind in ("fetch", "write"):
             w.writerow({k: r[k] for k in w.fieldnames})
 # the dominant kernel: the 256 x 256 pair-fill ring instantiations (bf16 inputs, either output type: the AlphaCLIP
 # QKV and FC2 products); rocprofv3 prints some names demangled and some not
-dominant = "2, 4, 8, 4, 2, 4, true>|Li2ELi4ELi8ELi4ELi2ELi4ELb1E"
+dominant = "2, 4, 8, 4, 2, 4, true, false>|Li2ELi4ELi8ELi4ELi2ELi4ELb1ELb0E"
 subprocess.check_call([sys.executable, "tools/pmc_traffic.py", f"{src}/fetch/{tag}_counter_collection.csv",
                        f"{src}/write/{tag}_counter_collection.csv", dominant, f"{dst}/{tag}_pmc_traffic.json"])
