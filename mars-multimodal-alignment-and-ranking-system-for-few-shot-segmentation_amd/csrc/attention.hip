@@ -89,6 +89,15 @@ __device__ __forceinline__ float rows_max(float x) {
     return vmax2(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
 }
 
+__device__ __forceinline__ float rows_sum(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    u = __builtin_bit_cast(unsigned, x);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -463,6 +472,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const __bf16* __
 // 32 queries per wave (two blocks of 16), four waves, K/V tiles of 64 keys double buffered as in the kernel above.
 // Full tiles after the first run on the absolute exp2 scale when the first tile allows it (head of the file);
 // the first tile, the ragged last one and everything after a range-check failure use the running maximum.
+//
+// LEAD1: sequences of 64 k + 1 tokens (a class token in front of a grid of patches: 577 for a 24 x 24 grid).
+// Tiled from key 0 they end in a tile with ONE key, which costs a whole trip round the loop - fill, barrier,
+// masks, the classic softmax, twenty matrix instructions on zeros.  Instead key 0 becomes the INITIAL STATE of
+// the online softmax, worked out on the vector ALU (a 64-long dot product per query: sixteen multiply-adds a
+// lane and a sum over the four lane rows; the output starts as p0 v0), and the tiles cover keys 1 .. T-1, all full.
+template <bool LEAD1>
 __global__ __launch_bounds__(256, 2) void flash_attn_pipe_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ O,
                                                                  float* __restrict__ lse, int T, int H, float c2) {
     constexpr int QB = 2, NW = 4, QPB = NW * QB * 16, PPW = 16 / NW;
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pipe_kernel(const __bf16* _
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wave * PPW + i;
-            const int key = min(t * KT + prow[i], T - 1);
+            const int key = min((LEAD1 ? 1 : 0) + t * KT + prow[i], T - 1);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(psrc[i] + (((unsigned)key & 0xffffffu) * (row_b24 & 0xffffffu))),
                                              (lds_ptr_t)(&lds[buf][p >> 3][(p & 7) * 1024]), 16, 0, 0);
         }
@@ -523,7 +539,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pipe_kernel(const __bf16* _
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-    const int nt = (T + KT - 1) / KT;
+    const int TK = LEAD1 ? T - 1 : T;                  // keys the tiles cover (LEAD1: a multiple of KT)
+    const int nt = (TK + KT - 1) / KT;
 
     // fragment addresses: per-lane base plus compile-time offsets (see the kernel above)
     const int ksw = (r16 >> 1) & 7;
@@ -701,11 +718,47 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pipe_kernel(const __bf16* _
         for (int m = 0; m < 4; ++m) read_v(0, m);
     }
     if (nt > 1) issue_tile(1, 1);
-    if (wave_active) part1_classic(0, std::false_type{}, std::true_type{});
-    tile_finish(0);
-    int t = 1;
+    if constexpr (LEAD1) {
+        if (wave_active) {
+            // key 0 as the initial state: s0 = q . k0 in the exp2 domain (the query fragments carry the scale)
+            const unsigned char* k0p = base + (int64_t)D * 2 + 16 * g;
+            const bf16x8 ka = __builtin_bit_cast(bf16x8, *(const uint4*)k0p);
+            const bf16x8 kb = __builtin_bit_cast(bf16x8, *(const uint4*)(k0p + 64));
+            float s0[QB];
+            bool ok = true;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    part = fmaf((float)qf[qb][0][e], (float)ka[e], part);
+                    part = fmaf((float)qf[qb][1][e], (float)kb[e], part);
+                }
+                s0[qb] = rows_sum(part);
+                ok = ok && fabsf(s0[qb]) <= ABS_RANGE;
+            }
+            lazy = __all(ok);                           // moderate scores: the reference of the absolute scale is 0
+            bf16x4 v0[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v0[m] = *(const bf16x4*)(base + (int64_t)D * 4 + 32 * m + 8 * g);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                mrun[qb] = lazy ? 0.f : s0[qb];
+                const float p0 = lazy ? __builtin_amdgcn_exp2f(s0[qb]) : 1.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[qb][m][j] = p0 * (float)v0[m][j];
+                o[qb][4] = (f32x4){p0, p0, p0, p0};
+            }
+        }
+    } else {
+        if (wave_active) part1_classic(0, std::false_type{}, std::true_type{});
+        tile_finish(0);
+    }
+    int t = LEAD1 ? 0 : 1;
     while (t < nt) {
-        const bool ragged = t * KT + KT > T;
+        const bool ragged = t * KT + KT > TK;
         if (wave_active) {
             if (lazy && !ragged) {
                 // a run of full tiles on the absolute scale
@@ -714,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_pipe_kernel(const __bf16* _
                     if (!part1_fast()) { fired = true; break; }
                     tile_finish(t);
                     ++t;
-                    if (t >= nt || t * KT + KT > T) break;
+                    if (t >= nt || t * KT + KT > TK) break;
                 }
                 if (!fired) continue;
                 lazy = false;
@@ -858,7 +911,10 @@ extern "C" int marship_flash_attn(const void* qkv, void* O, float* lse, int B, i
         hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, causal, score_scale_log2);
     } else {         // image towers: the same tiling with the pipelined tile loop
         dim3 grid((T + 127) / 128, B * H), block(256);
-        hipLaunchKernelGGL(flash_attn_pipe_kernel, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, score_scale_log2);
+        if (T % KT == 1 && flash_variant() != 2)   // a class token in front of whole tiles of patches (MARS_FLASH_VARIANT=2: tiled from key 0)
+            hipLaunchKernelGGL(flash_attn_pipe_kernel<true>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, score_scale_log2);
+        else
+            hipLaunchKernelGGL(flash_attn_pipe_kernel<false>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, score_scale_log2);
     }
     MARS_LAUNCH_CHECK();
     return 0;

@@ -579,6 +579,40 @@ def test_flash_attention_score_ranges(pkg, cuda, case):
     assert float(((lse[0] - want).abs() / want.abs().clamp_min(1.0)).max()) < 1.2e-2      # raw queries: scaled in the kernel
 
 
+@pytest.mark.parametrize("case", ["plain", "huge_key0", "very_negative_key0", "late_huge_spike", "key0_dominates", "two_heads_batch"])
+def test_flash_attention_class_token_sequences(pkg, cuda, case):
+    """Sequences of 64 k + 1 tokens: key 0 is the initial state of the online softmax (worked on the vector ALU) and
+    the tiles cover keys 1 .. T-1.  Every regime of that initial state - moderate (absolute scale), out of range either
+    way (running maximum from the start), a later score beyond the head room - against the f32 softmax."""
+    T, H, B = 321, 1, 1                             # key 0 + five full tiles
+    if case == "two_heads_batch":
+        T, H, B = 577, 2, 2
+    qkv = _rand((B * T, 192 * H), 31, cuda) * 0.5
+    if case != "two_heads_batch":
+        unit = qkv[7, 0:64] / qkv[7, 0:64].norm()
+        n7 = float(qkv[7, 0:64].norm())
+        if case == "huge_key0":                     # q7 . k0 / 8 = +60 nats: beyond the absolute range
+            qkv[0, 64:128] = unit * (8 * 60.0 / n7)
+        elif case == "very_negative_key0":
+            qkv[0, 64:128] = -unit * (8 * 60.0 / n7)
+        elif case == "late_huge_spike":             # +120 nats on a key of the fourth tile
+            qkv[200, 64:128] = unit * (8 * 120.0 / n7)
+        elif case == "key0_dominates":              # +30 nats: inside the range, every other probability tiny
+            qkv[0, 64:128] = unit * (8 * 30.0 / n7)
+    qkv = qkv.to(torch.bfloat16)
+    D = 64 * H
+    O = torch.zeros(B * T, D, device=cuda, dtype=torch.bfloat16)
+    lse = torch.zeros(B * H, T, device=cuda)
+    pkg.ops.flash_attn(qkv, O, lse, B, T, H, False)
+    q = qkv.float().view(B, T, 3, H, 64)
+    s = torch.einsum("bthd,bshd->bhts", q[:, :, 0], q[:, :, 1]) * 0.125
+    ref = torch.einsum("bhts,bshd->bthd", s.softmax(-1), q[:, :, 2]).reshape(B * T, D)
+    assert bool(torch.isfinite(O.float()).all())
+    assert float((O.float() - ref).abs().max()) < 3e-2
+    want = torch.logsumexp(s, -1).reshape(B * H, T)
+    assert float(((lse - want).abs() / want.abs().clamp_min(1.0)).max()) < 1.2e-2
+
+
 # ------------------------------------------------------------------ alignment / refinement
 def test_vva_prior_and_minmax(pkg, cuda):
     R, P, ld = 162, 81, 128
