@@ -212,7 +212,9 @@ static int pick_variant(const MarsGemm* g) {
         // few 128 x 128 tiles: halve the tile height to spread the work (bf16: up to about one tile per
         // CU, on the pair-fill shape; f32: up to about half the CUs)
         const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128) * g->nb0 * g->nb1;
-        if (v == 11 && t128 < 300) v = 10;
+        // (long products pay the smaller tile's extra operand bytes 128 steps long: 264 tiles at K = 4096, the rows
+        // of the AlphaCLIP fc2 beyond its full rounds, take 68 us on 128 x 128 against 79; 176 tiles 57 against 51)
+        if (v == 11 && t128 < (g->K >= 2048 ? 220 : 300)) v = 10;
         if (v == 6 && t128 < 150) v = 7;
     }
     return v;

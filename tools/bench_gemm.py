@@ -21,6 +21,7 @@ SHAPES = [
     ("aclip proj  ", 36928, 1024, 1024, torch.float32, "res"),
     ("aclip fc1   ", 36928, 4096, 1024, torch.bfloat16, "gelu"),
     ("aclip fc2   ", 36928, 1024, 4096, torch.float32, "res"),
+    ("fc2 tail    ", 4160, 1024, 4096, torch.float32, "res"),
     ("tails fc1 a ", 36864, 4096, 1024, torch.bfloat16, "gelu"),
     ("tails fc1 b ", 64, 4096, 1024, torch.bfloat16, "gelu"),
     ("tails qkv a ", 36864, 3072, 1024, torch.bfloat16, "bias"),
