@@ -579,7 +579,8 @@ def test_flash_attention_score_ranges(pkg, cuda, case):
     assert float(((lse[0] - want).abs() / want.abs().clamp_min(1.0)).max()) < 1.2e-2      # raw queries: scaled in the kernel
 
 
-@pytest.mark.parametrize("case", ["plain", "huge_key0", "very_negative_key0", "late_huge_spike", "key0_dominates", "two_heads_batch"])
+@pytest.mark.parametrize("case", ["plain", "huge_key0", "very_negative_key0", "late_huge_spike", "key0_dominates", "two_heads_batch",
+                                  "two_tiles", "three_tiles"])
 def test_flash_attention_class_token_sequences(pkg, cuda, case):
     """Sequences of 64 k + 1 tokens: key 0 is the initial state of the online softmax (worked on the vector ALU) and
     the tiles cover keys 1 .. T-1.  Every regime of that initial state - moderate (absolute scale), out of range either
@@ -587,8 +588,12 @@ def test_flash_attention_class_token_sequences(pkg, cuda, case):
     T, H, B = 321, 1, 1                             # key 0 + five full tiles
     if case == "two_heads_batch":
         T, H, B = 577, 2, 2
+    elif case == "two_tiles":                       # the shortest sequence this form takes
+        T, H, B = 129, 2, 2
+    elif case == "three_tiles":
+        T, H, B = 193, 1, 3
     qkv = _rand((B * T, 192 * H), 31, cuda) * 0.5
-    if case != "two_heads_batch":
+    if case in ("plain", "huge_key0", "very_negative_key0", "late_huge_spike", "key0_dominates"):
         unit = qkv[7, 0:64] / qkv[7, 0:64].norm()
         n7 = float(qkv[7, 0:64].norm())
         if case == "huge_key0":                     # q7 . k0 / 8 = +60 nats: beyond the absolute range
