@@ -51,6 +51,28 @@ def test_order_of_proposals_does_not_matter(full):
     assert torch.equal(pred, (kept.sum(0) > 0).float())
 
 
+def test_stages_side_by_side_equal_one_after_the_other(full, pkg):
+    """At the benchmark's size: the three stages queued side by side on their streams (the default) and one after the
+    other on the caller's stream give the same prediction and the same per-proposal quantities, bit for bit, on
+    consecutive episodes (the second and third reuse every buffer, stream and pinned slot of the first)."""
+    mars, _, _ = full
+    eps = []
+    for seed in (3, 8, 22):                         # 8 and 22: the episodes with the largest transport problems
+        ep = pkg.synth.make_episode(1000 * bench.FOLD + seed, size=bench.SIZE, nshot=1, nprop=bench.NPROP, fold=bench.FOLD)
+        eps.append({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ep.items()})
+    out = {}
+    try:
+        for concurrent in (True, False):
+            mars.concurrent = concurrent
+            out[concurrent] = [_run(mars, ep, ep["mask_proposals"]) + (mars.vva.clone(), mars.vta.clone()) for ep in eps]
+    finally:
+        mars.concurrent = True
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        for k in ("emd", "aclip", "cnt", "svv", "svt", "score", "order", "keep"):
+            assert torch.equal(a[1][k], b[1][k]), k
+
+
 def test_batch_split_and_exact_emd(full, pkg):
     mars, ep, _ = full
     fmm = mars.filtering_merging_component
