@@ -229,7 +229,7 @@ class FilteringMergingModule:
         ops.proposal_stats(w["bits"], N, P, vva.to(dev).contiguous().float().view(-1), vta.to(dev).contiguous().float().view(-1),
                            w["cnt"], w["svv"], w["svt"], w["ucnt"])
         # lines 90-97: the AlphaCLIP text features and the cosines (queued behind the batch)
-        prepared = getattr(self, "_prepared_text", None)
+        prepared, self._prepared_text = getattr(self, "_prepared_text", None), None      # taken once, never reused
         if prepared is not None and prepared[0] == tuple(text):
             tfeat = prepared[1]
             torch.cuda.current_stream(dev).wait_event(prepared[2])
@@ -243,12 +243,16 @@ class FilteringMergingModule:
         st["job"]["thread"].join()
         if st["job"]["error"] is not None:
             raise st["job"]["error"]
+        if w.get("emd_copied") is not None:
+            w["emd_copied"].synchronize()       # the copy of the call before has read the pinned buffer
         w["emd_host"].copy_(st["job"]["result"])
         w["emd"].copy_(w["emd_host"], non_blocking=True)
+        w["emd_copied"] = torch.cuda.Event()
+        w["emd_copied"].record()
         # lines 118-138, 213-217: combine, rank, keep
         ops.rank(w["emd"], w["aclip"], w["cnt"], w["svv"], w["svt"], w["ucnt"], N, self.alpha, self.static_threshold,
                  self.dynamic_threshold, w["score"], w["order"], w["keep"])
-        self.last = dict(w=w, masks=masks, N=N)
+        self.last = dict(w=w, masks=masks, N=N, tfeat=tfeat)     # tfeat: kept alive until the next call (it may live on another stream's pool)
         return w
 
     def _compute_emd_scores(self, cost_matrix, fg_host: torch.Tensor, bits_host: torch.Tensor) -> torch.Tensor:

@@ -96,12 +96,13 @@ class VisualTextAlignmentModule:
         T = (image.shape[-1] // self.model_patch_size) ** 2 + 1
         acc = self.pir.new_accumulator(T - 1)
         X, _ = self.model.encode_image_tokens(image[None], self._mean, self._std, mean_attn=(acc, self.last_n))
-        prepared = getattr(self, "_prepared", None)
+        prepared, self._prepared = getattr(self, "_prepared", None), None        # taken once, never reused
         if prepared is not None and prepared[0] == fg_label:
             text = prepared[1]
             torch.cuda.current_stream(self.device).wait_event(prepared[2])
         else:
             text = self.compute_text_feats(fg_label)
+        self.text_features = text           # kept alive until the next call (it may live on another stream's pool)
         L, H = self.model.cfg.vision_layers, self.model.cfg.vision_heads
         last = (acc, 1, T - 1, 1.0 / (min(self.last_n, L) * H)) if self.last_n >= 1 else None
         cam, logits, _ = self.model.gradcam(X, text, mean_attn=last)
