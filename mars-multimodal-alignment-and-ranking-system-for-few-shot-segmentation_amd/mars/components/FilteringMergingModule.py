@@ -115,12 +115,13 @@ class FilteringMergingModule:
                               vva, vta, text)
         return self._merge_masks(mask_proposals)
 
-    def begin(self, query_img, mask_proposals, support_mask, cost_matrix, patch_features_spatial_dimension: int):
+    def begin(self, query_img, mask_proposals, support_mask, cost_matrix, patch_features_spatial_dimension: int, on_block=None):
         """Starts the part of ``compute`` that needs neither prior, on the current stream: patch occupancy of
         the support masks and of the proposals with their copies to the host, the AlphaCLIP batch over the
         proposals, and - on a host thread of its own - the transport problems, which start as soon as the
         occupancy bits and the similarity matrix have reached the host.  ``compute`` with the same proposals
-        takes the result; anything else discards it."""
+        takes the result; anything else discards it.  ``on_block(i)`` is called when block i of the first
+        AlphaCLIP chunk has been queued (``MARS.predict`` issues the visual-visual tower there)."""
         dev = self.device
         if self._begun is not None:             # started and never taken: its solver still reads the pinned buffers
             if self._begun["job"]["thread"] is not None:
@@ -143,7 +144,7 @@ class FilteringMergingModule:
         if cost_matrix is not None:
             self._start_solver(job, cost_matrix)
         # lines 183-207: the AlphaCLIP visual features of every proposal
-        feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w)
+        feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w, on_block=on_block)
         self._begun = dict(key=(mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(),
                                 patch_features_spatial_dimension),
                            w=w, masks=masks, feats=feats, job=job, N=N, P=P)
@@ -196,7 +197,7 @@ class FilteringMergingModule:
         ops.resample_axis_u8(w["img_tmp"], C, S, res, 0, t, w["img_res"])
         return w["img_res"]
 
-    def _compute_alphaclip_vis_feats(self, image: torch.Tensor, masks: torch.Tensor, w: Optional[dict] = None) -> torch.Tensor:
+    def _compute_alphaclip_vis_feats(self, image: torch.Tensor, masks: torch.Tensor, w: Optional[dict] = None, on_block=None) -> torch.Tensor:
         """Lines 183-207: one AlphaCLIP pass per proposal (batched), un-normalised features [N, E]."""
         N, S, _ = masks.shape
         if w is None:
@@ -211,7 +212,7 @@ class FilteringMergingModule:
             # mask branch (backbone_loader.py:182-186): u8 quantise, bilinear antialiased resize, (x-0.5)/0.26
             ops.resample_axis(chunk, n, S, S, 1, t, w["a_tmp"], quant_u8=True)
             ops.resample_axis(w["a_tmp"], n, S, res, 0, t, w["alpha"], shift=0.5, scale=0.26)
-            f = self.alpha_clip_model.visual(img, w["alpha"][:n], mean=self._mean, std=self._std)
+            f = self.alpha_clip_model.visual(img, w["alpha"][:n], mean=self._mean, std=self._std, **({"on_block": on_block} if on_block is not None and i == 0 else {}))
             w["feats"][i:i + n].copy_(f)
         return w["feats"]
 

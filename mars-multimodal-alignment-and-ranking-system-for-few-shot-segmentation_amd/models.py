@@ -187,8 +187,10 @@ class Tower:
         return P
 
 
-def _blocks_forward_folded(self, x: torch.Tensor, blocks: List[Block]) -> None:
+def _blocks_forward_folded(self, x: torch.Tensor, blocks: List[Block], on_block=None) -> None:
     """``block_forward`` over a run of blocks built with ``fold=True``: no LayerNorm pass reads the stream.
+    ``on_block(i)`` is called when block i has been queued (a caller with work for other streams can issue it
+    between the blocks instead of behind all of them).
     Inside the run the f32 stream lives in two bf16 planes, hi = bf16(x) and lo = bf16(x - hi).  The products
     that add to it (attention projection, second MLP layer) read and write the planes and leave the row sums;
     the products that would have read normalised rows (qkv, first MLP layer) take the hi plane and apply mean
@@ -217,6 +219,8 @@ def _blocks_forward_folded(self, x: torch.Tensor, blocks: List[Block]) -> None:
             ops.ln_finish(part, M, D, blocks[i + 1].ln1.eps, stat)
         else:
             ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, ln_out=(hi, lo, None))
+        if on_block is not None:
+            on_block(i)
 
 
 Tower.blocks_forward_folded = _blocks_forward_folded
@@ -663,9 +667,10 @@ class AlphaCLIP(_TextTower):
         self._bufs: Dict[int, dict] = {}
         self.input_resolution = cfg.image_resolution
 
-    def visual(self, image: torch.Tensor, alpha: torch.Tensor, image_u8: bool = False, mean=None, std=None) -> torch.Tensor:
+    def visual(self, image: torch.Tensor, alpha: torch.Tensor, image_u8: bool = False, mean=None, std=None, on_block=None) -> torch.Tensor:
         """model.visual(image, alpha) (alpha_clip/model.py:358-386).  ``image`` is [n,3,R,R] or [1,3,R,R]
-        (one image shared by all alpha planes: its patch embedding is computed once and broadcast)."""
+        (one image shared by all alpha planes: its patch embedding is computed once and broadcast).
+        ``on_block(i)``: called when transformer block i has been queued."""
         cfg = self.cfg
         n = alpha.shape[0]
         p, D, R = cfg.vision_patch_size, cfg.vision_width, cfg.image_resolution
@@ -707,10 +712,12 @@ class AlphaCLIP(_TextTower):
         X2 = X.view(n * T, D)
         ops.layernorm(X2, self.ln_pre.w, self.ln_pre.b, X2, self.ln_pre.eps)
         if self.fold_ln and len(self.vtower.blocks) > 1:
-            self.vtower.blocks_forward_folded(X, self.vtower.blocks[:-1])
+            self.vtower.blocks_forward_folded(X, self.vtower.blocks[:-1], on_block=on_block)
         else:
-            for blk in self.vtower.blocks[:-1]:
+            for i, blk in enumerate(self.vtower.blocks[:-1]):
                 self.vtower.block_forward(X, blk)
+                if on_block is not None:
+                    on_block(i)
         if self.first_token_last_block:
             cls_rows = self.vtower.block_forward_first_token(X, self.vtower.blocks[-1])   # only the class token is read below
         else:
