@@ -144,7 +144,8 @@ class FilteringMergingModule:
         if cost_matrix is not None:
             self._start_solver(job, cost_matrix)
         # lines 183-207: the AlphaCLIP visual features of every proposal
-        feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w, on_block=on_block)
+        hook = {"on_block": on_block} if on_block is not None else {}      # (subclasses may override without the hook)
+        feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w, **hook)
         self._begun = dict(key=(mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(),
                                 patch_features_spatial_dimension),
                            w=w, masks=masks, feats=feats, job=job, N=N, P=P)
