@@ -279,46 +279,56 @@ def main():
     miou, fb_iou, _ = meter.compute_iou()
 
     if rank == 0:
-        # Every MFMA GEMM launch of the sampled step was timed with events on its stream.  The dominant
+        # Every MFMA GEMM launch of a sampled step was timed with events on its stream.  The dominant
         # kernel is the ring shape with the largest summed time (the AlphaCLIP products run on three of them:
-        # 256 x 256 with pair fills for QKV and FC2, 256 x 128 for FC1, 128 x 128 for the projection); every launch,
+        # 256 x 256 with pair fills for QKV, FC1 and FC2, 128 x 128 for the projection); every launch,
         # the smaller shapes of the two alignment towers included, is summed under "all_gemm".
-        timed = [(p[0].elapsed_time(p[1]), p[2], p[3]) for p in prof]
-        by_variant = {}
-        for t in timed:
-            by_variant[t[2]] = by_variant.get(t[2], 0.0) + t[0]
-        dom_variant = max(by_variant, key=by_variant.get) if by_variant else None
-        dom = [t for t in timed if t[2] == dom_variant] or timed
-        flops, ms = sum(t[1] for t in dom), sum(t[0] for t in dom)
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        ms_all = sum(t[0] for t in timed)
-        all_gemm = {"achieved": sum(t[1] for t in timed) / (ms_all * 1e-3) / 1e12 if ms_all > 0 else 0.0, "launches": len(timed),
-                    "share_of_step": ms_all / (elapsed / args.steps * 1e3)}
+        def summarise(profile):
+            timed = [(p[0].elapsed_time(p[1]), p[2], p[3]) for p in profile]
+            by_variant = {}
+            for t in timed:
+                by_variant[t[2]] = by_variant.get(t[2], 0.0) + t[0]
+            dom_v = max(by_variant, key=by_variant.get) if by_variant else None
+            dom = [t for t in timed if t[2] == dom_v] or timed
+            flops, ms = sum(t[1] for t in dom), sum(t[0] for t in dom)
+            ms_all = sum(t[0] for t in timed)
+            return dict(variant=dom_v, launches=len(dom), ms=ms, achieved=flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                        all_achieved=sum(t[1] for t in timed) / (ms_all * 1e-3) / 1e12 if ms_all > 0 else 0.0,
+                        all_launches=len(timed), all_ms=ms_all)
+
+        step_ms = elapsed / args.steps * 1e3
+        in_step = summarise(prof)
+        # In the timed steps the stages of a query run side by side, so an event pair around a launch of the batch also
+        # spans the share of the chip that other streams' kernels took meanwhile.  The kernel's own rate is the one of
+        # the extra step (same workload, same launches, nothing beside them): that is also what a kernel trace of this
+        # command reports per launch.  Without such a step (stages already one after the other) both are the same.
+        alone = summarise(prof_serial) if prof_serial else in_step
+        dom_variant = alone["variant"]
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-        serial = [(p[0].elapsed_time(p[1]), p[2]) for p in prof_serial if p[3] == dom_variant]
-        serial_ms = sum(t[0] for t in serial)
-        achieved_serial = sum(t[1] for t in serial) / (serial_ms * 1e-3) / 1e12 if serial_ms > 0 else None
         # HBM-side bytes were counted (stored counter passes) on the pair-fill 256x256 kernel only
         traffic, traffic_src = pmc_traffic() if args.dtype == "bf16" and dom_variant == 8 else (None, None)
         out = {
             "metric": "query images/sec", "value": args.steps * world / elapsed, "unit": "query images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype + ("+fp8-attention" if args.fp8_attention else ""), "data": "synthetic",
             "config": {"workload": "COCO-20i fold0 1-shot, DINOv2-L/14-reg4@518 + CLIP ViT-B/16 GradCAM + AlphaCLIP ViT-L/14@336, "
                                    "64 proposals, exact EMD, rank+merge+IoU (BASELINE configs[1])",
                        "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}", "rccl_ranks": ranks_joined},
             "miou": float(miou), "fb_iou": float(fb_iou),
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "roofline": {"bound": "mfma", "achieved": alone["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": alone["achieved"] / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": RING_KERNELS.get(dom_variant, f"gemm variant {dom_variant}").replace(
                              "<bf16,", "<bf16," if args.dtype == "bf16" else "<f32,"),
-                         "launches": len(dom), "avg_launch_us": ms * 1e3 / max(len(dom), 1), "sampled_steps": 1,
-                         "share_of_step": ms / (elapsed / args.steps * 1e3), "all_gemm": all_gemm,
-                         # the same launches in an extra, untimed step with nothing running beside them
-                         "achieved_alone": achieved_serial, "frac_alone": achieved_serial / peak if achieved_serial else None,
-                         "note": "achieved: event-timed launches of the timed region, where smaller kernels of other stages share the chip; "
-                                 "achieved_alone: the same launches in one extra untimed step with the stages queued one after the other"},
+                         "launches": alone["launches"], "avg_launch_us": alone["ms"] * 1e3 / max(alone["launches"], 1), "sampled_steps": 1,
+                         "sampled": ("one extra step right after the timed region with the stages of the query queued one after the other: "
+                                     "the launches of the kernel with nothing beside them" if prof_serial else "the last timed step"),
+                         "share_of_step": alone["ms"] / step_ms,
+                         "all_gemm": {"achieved": alone["all_achieved"], "launches": alone["all_launches"], "share_of_step": alone["all_ms"] / step_ms},
+                         # the same event pairs in the last TIMED step, where kernels of the other stages share the chip with the launch
+                         "in_timed_step": {"achieved": in_step["achieved"], "frac": in_step["achieved"] / peak,
+                                           "avg_launch_us": in_step["ms"] * 1e3 / max(in_step["launches"], 1), "launches": in_step["launches"],
+                                           "all_gemm_achieved": in_step["all_achieved"]}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, sds)
