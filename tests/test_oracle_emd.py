@@ -66,6 +66,33 @@ def test_product_emd_scores_batch(pkg):
     assert float((got - got2).abs().max()) < 1e-12
 
 
+def test_product_emd_scores_float_costs_and_vector_tails(pkg):
+    """The batch entry prices float32 costs with a vector minimum over whole rows: every tail length of that
+    loop (numbers of sinks from 1 to 11, and around 128) and costs with the structure of the path's own (cosines
+    of correlated features) against the double-precision single-problem entry and the oracle's solver."""
+    import torch
+    ops, lib = pkg.ops, pkg.hip.lib()
+    rng = np.random.default_rng(11)
+    R, P = 90, 140
+    f_s = rng.normal(size=(R, 24)) + 2.0 * rng.normal(size=(1, 24))
+    f_q = rng.normal(size=(P, 24)) + 2.0 * rng.normal(size=(1, 24))
+    f_s /= np.linalg.norm(f_s, axis=1, keepdims=True)
+    f_q /= np.linalg.norm(f_q, axis=1, keepdims=True)
+    S = torch.from_numpy(np.pad((f_s @ f_q.T).astype(np.float32), ((0, 0), (0, 192 - P))))
+    fg = torch.from_numpy((rng.random(R) < 0.6).astype(np.uint8))
+    sizes = list(range(1, 12)) + [127, 128, 129, 131, P]
+    bits = torch.zeros(len(sizes), P, dtype=torch.uint8)
+    for k, m in enumerate(sizes):
+        bits[k, torch.from_numpy(rng.permutation(P)[:m].copy())] = 1
+    got = ops.emd_scores_host(S, fg, bits, threads=4)
+    C = ((1 - S[:, :P]) / 2).numpy()
+    for k, m in enumerate(sizes):
+        M = np.ascontiguousarray(C[fg.numpy().astype(bool)][:, bits[k].numpy().astype(bool)].astype(np.float64))
+        one = lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), M.shape[0], M.shape[1])
+        assert abs(float(got[k]) - (1 - one)) < 1e-12, m
+        assert abs(one - emd2_uniform(M)) < 1e-10, m
+
+
 def test_product_simplex_rejects_non_finite_costs(pkg):
     """A NaN or infinite cost has no transport optimum: the answer is NaN, promptly, instead of a
     pivoting sequence on comparisons that no longer order anything."""
