@@ -22,6 +22,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <immintrin.h>
 #include <limits>
 #include <numeric>
@@ -80,7 +81,8 @@ __attribute__((target("avx2"))) static double row_min_avx2(const float* row, con
     for (; j < m; ++j) { const double x = (double)row[j] - v[j]; r = x < r ? x : r; }
     return r;
 }
-static const bool g_avx2 = __builtin_cpu_supports("avx2");
+// MARS_EMD_NO_AVX2 in the environment keeps the SSE2 loop (so that both can be tested on one machine)
+static const bool g_avx2 = __builtin_cpu_supports("avx2") && !getenv("MARS_EMD_NO_AVX2");
 template <typename CT> static inline double row_min(const CT* row, const double* v, int m) {
     return g_avx2 ? row_min_avx2(row, v, m) : row_min_sse2(row, v, m);
 }

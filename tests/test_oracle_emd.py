@@ -93,6 +93,30 @@ def test_product_emd_scores_float_costs_and_vector_tails(pkg):
         assert abs(one - emd2_uniform(M)) < 1e-10, m
 
 
+def test_product_simplex_sse2_pricing_loop():
+    """The pricing loop exists twice (AVX2 where the CPU has it, SSE2 otherwise): the SSE2 form, forced through
+    the environment in a process of its own, gives the same optima."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from __graft_entry__ import load_package\n"
+        "from oracle.emd import emd2_uniform\n"
+        "lib = load_package(require_native=True).hip.lib()\n"
+        "rng = np.random.default_rng(2)\n"
+        "for n, m in ((5, 1), (7, 3), (40, 37), (64, 130)):\n"
+        "    M = np.ascontiguousarray(rng.random((n, m)))\n"
+        "    got = lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), n, m)\n"
+        "    assert abs(got - emd2_uniform(M)) < 1e-10, (n, m)\n"
+        "print('ok')\n" % root)
+    env = dict(os.environ, MARS_EMD_NO_AVX2="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_product_simplex_rejects_non_finite_costs(pkg):
     """A NaN or infinite cost has no transport optimum: the answer is NaN, promptly, instead of a
     pivoting sequence on comparisons that no longer order anything."""
