@@ -5,6 +5,7 @@
 """
 from __future__ import annotations
 
+import inspect
 import os
 import time
 from typing import Dict, Optional
@@ -111,9 +112,9 @@ class MARS:
                     with torch.cuda.stream(st["high"]):
                         queued["vva"] = vva_mod.compute(support_imgs=support_images, support_masks=support_masks, query_img=query_image)
 
-            try:
+            if "on_block" in inspect.signature(fmm.begin).parameters:
                 fmm.begin(query_image, mask_proposals, support_masks, None, G, on_block=queue_vva)
-            except TypeError:                   # a filtering module whose begin() takes no hook
+            else:                               # a filtering module whose begin() takes no hook
                 fmm.begin(query_image, mask_proposals, support_masks, None, G)
             if "vva" not in queued:             # fewer blocks than that, or no hook: behind the whole batch
                 queue_vva(self.vva_after_block)
