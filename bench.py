@@ -24,7 +24,35 @@ import sys
 import time
 import types
 
-import torch
+
+def rank_cpu_slice(cpus, local_rank: int, local_world: int):
+    """The cores rank ``local_rank`` of ``local_world`` ranks on this node keeps: the sorted core list cut into
+    ``local_world`` runs of equal length (neighbouring core numbers share caches and a memory controller), the
+    remainder left unused so that every rank has the same number.  Fewer cores than ranks: the list as it is."""
+    cpus = sorted(cpus)
+    per = len(cpus) // max(local_world, 1)
+    if local_world <= 1 or per < 1:
+        return cpus
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank_cpus():
+    """Gives this rank a slice of the node's cores of its own (the transport solver's threads and torch's
+    pools inherit it), before torch starts any thread.  MARS_BENCH_PIN=0 leaves the mask alone."""
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    lr = int(os.environ.get("LOCAL_RANK", "0") or 0)
+    if lw <= 1 or os.environ.get("MARS_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    mine = rank_cpu_slice(os.sched_getaffinity(0), lr, lw)
+    os.sched_setaffinity(0, mine)
+    os.environ["MARS_RANK_PINNED"] = "1"          # default_emd_threads: the mask is already this rank's share
+    return mine
+
+
+if __name__ == "__main__":
+    pin_rank_cpus()
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,6 +60,9 @@ from __graft_entry__ import load_package  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
 NPROP, SIZE, FOLD = 64, 518, 0
+# Rehearsal of the N > 1 path on a one-GPU machine (tests only): every rank uses GPU 0 and the ranks meet over gloo.
+# The line such a run prints says so ("shared_gpu": true); it is not a scaling measurement.
+SHARE_GPU = os.environ.get("MARS_BENCH_SHARE_GPU", "0") == "1"
 # kernel instantiation behind each launch-policy variant (csrc/gemm.hip, csrc/gemm3.hip)
 RING_KERNELS = {3: "gemm_tn_ring_kernel<bf16, *, 2, 4, 8, 4, 2, 3> (256x256 tile)",
                 5: "gemm_tn_ring_kernel<bf16, *, 2, 2, 8, 4, 2, 3> (256x128 tile)",
@@ -50,39 +81,111 @@ def rank_episodes(rank: int, world: int, per_rank: int):
     return [k * world + rank for k in range(per_rank)]
 
 
+def _all_reduce(t, op):
+    """all_reduce of a small tensor; a gloo group (CPU tests, the one-card rehearsal) reduces a host copy."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        t = t.cpu()
+    dist.all_reduce(t, op=op)
+    return t
+
+
 def reduce_over_ranks(meter, elapsed: float, device, world: int) -> float:
     """The run's only collectives: SUM of the meter's [2, nclass] count buffers, MAX of the ranks' elapsed
     seconds (returned).  With one rank nothing is exchanged."""
     import torch.distributed as dist
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        el = _all_reduce(el, dist.ReduceOp.MAX)
         meter.all_reduce()
     return float(el)
 
 
-def launch_ranks(n: int, argv) -> int:
-    """Start ``n`` ranks of this file as child processes (this process has not touched the GPU and never
-    does) with the rendezvous variables a launcher would set; returns the first non-zero exit status."""
-    import socket
+def visible_gpus():
+    """GPUs the ranks will see, found WITHOUT any HIP or torch.cuda call (the launching process must never
+    initialise the runtime): the visibility lists a launcher or the box sets, else the compute nodes with
+    SIMDs in the KFD topology.  None when neither can be read - then the ranks check for themselves."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        n += int(props.get("simd_count", "0")) > 0
+    return n
+
+
+def gather_host_side(host: dict, device, world: int):
+    """Per rank: [mean solver ms, max solver ms, mean and max over steps of (step ms - ms at which the solver was
+    done, both from the start of the step), mean step ms, cores in the rank's mask] - gathered (a SUM of one-hot
+    rows: the same collective as the counts) so that rank 0 can say whether a rank's steps were held up by its
+    host solver (slack of a millisecond or less: the GPU's ranking and merge behind the batch) or by its GPU."""
+    import torch.distributed as dist
+    n = max(len(host["step_ms"]), 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    slack = [a - b for a, b in zip(host["step_ms"], host["emd_end_ms"])] or [0.0]
+    row = [sum(host["emd_ms"]) / n, max(host["emd_ms"] or [0.0]), sum(slack) / n, min(slack), sum(host["step_ms"]) / n, float(cores)]
+    table = torch.zeros(world, len(row), dtype=torch.float64, device=device)
+    table[int(os.environ.get("RANK", "0")) if world > 1 else 0] = torch.tensor(row, dtype=torch.float64, device=device)
+    if world > 1:
+        table = _all_reduce(table, dist.ReduceOp.SUM)
+    return table.cpu().tolist()
+
+
+def launch_ranks(n: int, argv, script=None, deadline_s=None, poll_s=0.05) -> int:
+    """Start ``n`` ranks of this file (or of ``script``) as child processes - this process has not touched the
+    GPU and never does - and watch them all at once: the first rank that exits non-zero ends the run (the
+    others are terminated, then killed, and that status is returned), and so does ``deadline_s`` (status
+    124).  The ranks meet through a file store in a directory of their own, so no port is picked here that
+    another process could take before rank 0 binds it."""
+    import shutil
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import tempfile
+    deadline_s = float(os.environ.get("MARS_BENCH_DEADLINE", "1500")) if deadline_s is None else deadline_s
+    store = tempfile.mkdtemp(prefix="mars_bench_rdzv_")
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:
-        for p in procs:
-            if p.poll() is None:
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MARS_BENCH_STORE=os.path.join(store, "store"))
+            # GPU buffers are shared between processes through dmabuf handles on this platform; the legacy IPC
+            # mode fails in hipIpcGetMemHandle, and RCCL opens its peers' buffers that way
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+        t_end = time.monotonic() + deadline_s
+        rc = 0
+        while rc == 0 and any(p.poll() is None for p in procs):
+            rc = next((p.returncode for p in procs if p.poll() not in (None, 0)), 0)
+            if rc == 0 and time.monotonic() > t_end:
+                print(f"bench: ranks still running after {deadline_s:.0f} s, stopping them", file=sys.stderr, flush=True)
+                rc = 124
+            if rc == 0:
+                time.sleep(poll_s)
+        rc = rc or next((p.returncode for p in procs if p.returncode), 0)
+        return rc
+    finally:
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_kill = time.monotonic() + 5.0
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.0, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
                 p.kill()
-    return rc
+                p.wait()
+        shutil.rmtree(store, ignore_errors=True)
 
 
 def host_cores() -> int:
@@ -198,21 +301,29 @@ def main():
     if args.gpus < 1:
         sys.exit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher: start the ranks here, before anything in this process touches the GPU
-        visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
-        if visible < args.gpus:
+        # no launcher: start the ranks here; this process makes no HIP or torch.cuda call, before or after
+        visible = visible_gpus()
+        if visible is not None and visible < args.gpus and not SHARE_GPU:
             sys.exit(f"--gpus {args.gpus} but only {visible} GPU(s) are visible")
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if SHARE_GPU else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    if local >= torch.cuda.device_count():
+        sys.exit(f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # ranks started by launch_ranks meet through its file store, ranks of a launcher through MASTER_ADDR / MASTER_PORT
+        store = os.environ.get("MARS_BENCH_STORE")
+        kw = dict(init_method="file://" + store) if store else {}
+        if SHARE_GPU:       # rehearsal on one card: RCCL refuses two ranks on a device, gloo carries the reduction
+            dist.init_process_group("gloo", rank=rank, world_size=world, **kw)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **kw)
 
     pkg = load_package(require_native=True)
     from importlib import import_module
@@ -235,11 +346,18 @@ def main():
         ep = pkg.synth.make_episode(1000 * FOLD + e, size=SIZE, nshot=1, nprop=NPROP, fold=FOLD)
         eps.append({k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in ep.items()})
 
+    host = {"emd_ms": [], "emd_end_ms": [], "step_ms": []}       # per timed step of this rank
+
     def step(ep, count=True):
+        t_s = time.perf_counter()
         pred = mars.predict(ep["support_imgs"], ep["support_masks"], ep["query_img"], ep["mask_proposals"])
         ai, au = Evaluator.classify_prediction(pred[None], ep)
         if count:
             meter.update(ai, au, ep["class_id"])
+            tm = getattr(mars.filtering_merging_component, "timing", {})
+            host["emd_ms"].append(tm.get("emd_ms", 0.0))
+            host["emd_end_ms"].append(tm.get("emd_end_ms", 0.0))
+            host["step_ms"].append(1e3 * (time.perf_counter() - t_s))     # predict() ends with a device synchronize
         mars.clear()
 
     for k in range(args.warmup):
@@ -275,6 +393,7 @@ def main():
         mars.concurrent = True
 
     elapsed = reduce_over_ranks(meter, elapsed, dev, world)
+    host_all = gather_host_side(host, dev, world)
     ranks_joined = dist.get_world_size() if world > 1 else 1          # what RCCL itself reports
     miou, fb_iou, _ = meter.compute_iou()
 
@@ -314,8 +433,15 @@ def main():
             "dtype": args.dtype + ("+fp8-attention" if args.fp8_attention else ""), "data": "synthetic",
             "config": {"workload": "COCO-20i fold0 1-shot, DINOv2-L/14-reg4@518 + CLIP ViT-B/16 GradCAM + AlphaCLIP ViT-L/14@336, "
                                    "64 proposals, exact EMD, rank+merge+IoU (BASELINE configs[1])",
-                       "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}", "rccl_ranks": ranks_joined},
+                       "episodes_per_gpu": args.steps, "proposals": NPROP, "parallelism": f"episode-sharded x{world}", "rccl_ranks": ranks_joined,
+                       **({"shared_gpu": True, "note": "rehearsal: all ranks on GPU 0 over gloo, not a scaling measurement"} if SHARE_GPU else {})},
             "miou": float(miou), "fb_iou": float(fb_iou),
+            # host side of every rank: the exact-EMD solver runs on host threads beside the GPU's proposal batch; a step whose
+            # solver was done less than about a millisecond before the step ended (slack) was bound by the rank's cores
+            "host": {"emd_threads": getattr(mars.filtering_merging_component, "emd_threads", None),
+                     "pinned": os.environ.get("MARS_RANK_PINNED", "0") == "1",
+                     "per_rank": [dict(zip(("emd_ms", "emd_ms_max", "emd_slack_ms", "emd_slack_ms_min", "step_ms", "cores"), [round(x, 3) for x in r]))
+                                  for r in host_all]},
             "roofline": {"bound": "mfma", "achieved": alone["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": alone["achieved"] / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": RING_KERNELS.get(dom_variant, f"gemm variant {dom_variant}").replace(

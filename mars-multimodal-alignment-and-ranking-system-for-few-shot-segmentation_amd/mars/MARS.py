@@ -123,7 +123,7 @@ class MARS:
             if handle is not None:
                 fmm.start_solver(handle)
             vta_mod.prepare_text(name, st["text0"])
-            fmm.prepare_text(text_alpha_clip, st["text1"])
+            fmm.prepare_text(text_alpha_clip, st.get("text1", st["text0"]))
             with torch.cuda.stream(st["vta"]):
                 vta = vta_mod.compute(query_image=query_image, fg_label=name, bg_labels=[])
                 vta_g = self._text_prior_on_visual_grid(vta, vva.shape[0], dev)
@@ -165,7 +165,12 @@ class MARS:
     def _get_streams(self, dev):
         if self._streams is None or self._streams["device"] != dev:
             side = lambda: torch.cuda.Stream(device=dev)      # noqa: E731
-            self._streams = dict(device=dev, high=torch.cuda.Stream(device=dev, priority=-1), vta=side(), text0=side(), text1=side())
+            # A process has four hardware queues on this platform: the caller's stream, the tower's, the text-alignment
+            # tower's and ONE for both prompt encoders keep every stream on a queue of its own (a fifth would share a
+            # queue with one of the others, which one being the runtime's choice).  MARS_TEXT_STREAMS=2: one each.
+            self._streams = dict(device=dev, high=torch.cuda.Stream(device=dev, priority=-1), vta=side(), text0=side())
+            if os.environ.get("MARS_TEXT_STREAMS", "1") == "2":
+                self._streams["text1"] = side()
         return {k: v for k, v in self._streams.items() if k != "device"}
 
     def clear(self):

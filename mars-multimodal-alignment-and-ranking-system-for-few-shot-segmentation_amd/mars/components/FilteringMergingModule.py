@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import os
 import threading
+import time
 from typing import Callable, Dict, List, Optional, Union
 
 import torch
@@ -32,12 +33,15 @@ from .VisualTextAlignmentModule import CLIP_MEAN, CLIP_STD
 def default_emd_threads() -> int:
     """Host threads for the transport solver of one process: the cores this process may run on (at most
     16: a query has 64 problems and the solver stops scaling there), shared evenly between the ranks that
-    a launcher placed on this node (LOCAL_WORLD_SIZE, else WORLD_SIZE)."""
+    a launcher placed on this node (LOCAL_WORLD_SIZE, else WORLD_SIZE) - unless the rank was already given a
+    core range of its own (MARS_RANK_PINNED=1: the mask is this rank's share)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    if os.environ.get("MARS_RANK_PINNED", "0") == "1":
+        ranks = 1
     return max(1, min(16, cores // max(ranks, 1)))
 
 
@@ -62,6 +66,7 @@ class FilteringMergingModule:
         self._tables: Dict = {}
         self._ws: Dict = {}
         self.last = {}
+        self.timing: dict = {}
         self._begun: Optional[dict] = None
 
     # ---------------------------------------------------------------- tables / buffers
@@ -140,16 +145,26 @@ class FilteringMergingModule:
         w["fg_host"].copy_(w["sbits"], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        job = dict(result=None, error=None, thread=None, ready=ev, w=w)
+        job = dict(result=None, error=None, thread=None, ready=ev, w=w, t_begin=time.perf_counter())
         if cost_matrix is not None:
             self._start_solver(job, cost_matrix)
         # lines 183-207: the AlphaCLIP visual features of every proposal
         hook = {"on_block": on_block} if on_block is not None else {}      # (subclasses may override without the hook)
         feats = self._compute_alphaclip_vis_feats(query_img[0].to(dev), masks, w, **hook)
-        self._begun = dict(key=(mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(),
-                                patch_features_spatial_dimension),
+        self._begun = dict(key=self._input_key(query_img, mask_proposals, support_mask, patch_features_spatial_dimension),
                            w=w, masks=masks, feats=feats, job=job, N=N, P=P)
         return self._begun
+
+    @staticmethod
+    def _input_key(query_img, mask_proposals, support_mask, G: int):
+        """What ``compute`` must be given to take over the work ``begin`` started: the very same three tensor
+        objects (held here, so their ids cannot be reused), unmodified since (their version counters), and the
+        same grid.  Another tensor at the same address, or the same one written to in between, starts over."""
+        return tuple((t, t._version) for t in (query_img, mask_proposals, support_mask)) + (G,)
+
+    @staticmethod
+    def _same_inputs(a, b) -> bool:
+        return len(a) == len(b) and a[-1] == b[-1] and all(x[0] is y[0] and x[1] == y[1] for x, y in zip(a[:-1], b[:-1]))
 
     def start_solver(self, cost_matrix):
         """The transport problems of the work ``begin`` started without a similarity matrix (``cost_matrix=None``)."""
@@ -166,7 +181,10 @@ class FilteringMergingModule:
         def solve():
             try:
                 job["ready"].synchronize()
+                t0 = time.perf_counter()
                 job["result"] = self._compute_emd_scores(cost_matrix, w["fg_host"], w["bits_host"])
+                job["solve_s"] = time.perf_counter() - t0       # inputs on the host -> all problems solved
+                job["end_s"] = time.perf_counter() - job["t_begin"]     # since the proposal stage was started
             except BaseException as exc:        # handed to the caller of compute()
                 job["error"] = exc
 
@@ -220,7 +238,7 @@ class FilteringMergingModule:
     def _score_proposals(self, query_img, mask_proposals, support_mask, cost_matrix, G: int, vva, vta, text):
         dev = self.device
         st, self._begun = self._begun, None
-        if st is not None and st["key"] != (mask_proposals.data_ptr(), tuple(mask_proposals.shape), support_mask.data_ptr(), G):
+        if st is not None and not self._same_inputs(st["key"], self._input_key(query_img, mask_proposals, support_mask, G)):
             if st["job"]["thread"] is not None:
                 st["job"]["thread"].join()      # started for other inputs: let it finish, then start over
             st = None
@@ -242,9 +260,15 @@ class FilteringMergingModule:
         # while the batch is still running and the GPU goes from the batch to the ranking without the host
         if st["job"]["thread"] is None:
             self._start_solver(st["job"], cost_matrix)
+        t_join = time.perf_counter()
         st["job"]["thread"].join()
         if st["job"]["error"] is not None:
             raise st["job"]["error"]
+        # how long the solver took, when it was done (since begin(): compare with the step's length - the GPU needs
+        # about a millisecond behind the batch for ranking and merge, so a solver done later than that held the
+        # step up) and how long the host stood here for it after queueing everything else
+        self.timing = dict(emd_ms=1e3 * st["job"].get("solve_s", 0.0), emd_end_ms=1e3 * st["job"].get("end_s", 0.0),
+                           emd_wait_ms=1e3 * (time.perf_counter() - t_join), emd_threads=self.emd_threads)
         if w.get("emd_copied") is not None:
             w["emd_copied"].synchronize()       # the copy of the call before has read the pinned buffer
         w["emd_host"].copy_(st["job"]["result"])

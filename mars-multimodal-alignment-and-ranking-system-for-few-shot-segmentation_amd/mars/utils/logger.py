@@ -9,6 +9,20 @@ import torch
 NCLASS = {"pascal": 20, "pascal5i": 20, "coco": 80, "fss": 1000, "paco_part": 448, "pascal_part": 100, "lvis": 1203}
 
 
+def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
+    """In-place all-reduce of ``t`` over the default group.  RCCL reduces device tensors where they are; a gloo
+    group (CPU runs, rehearsals of several ranks on one card) gets a host copy and the result is copied back."""
+    import torch.distributed as dist
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 class AverageMeter:
     def __init__(self, dataset, device="cuda"):
         """``dataset`` needs ``benchmark`` and ``class_ids`` (the fold's classes), as the reference's
@@ -36,8 +50,8 @@ class AverageMeter:
         is exact and order independent): the only collective of a data-parallel run."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.intersection_buf, op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.union_buf, op=dist.ReduceOp.SUM)
+            all_reduce_(self.intersection_buf, dist.ReduceOp.SUM)
+            all_reduce_(self.union_buf, dist.ReduceOp.SUM)
 
     def compute_iou(self):
         iou = self.intersection_buf / torch.max(torch.stack([self.union_buf, self.ones]), dim=0)[0]

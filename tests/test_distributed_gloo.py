@@ -101,6 +101,85 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    if torch.cuda.device_count() < 2:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
-        assert r.returncode != 0 and "visible" in r.stderr
+    env["HIP_VISIBLE_DEVICES"] = "0"                 # one visible GPU, whatever the machine has
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "visible" in r.stderr
+
+
+def test_visible_gpus_makes_no_gpu_call(monkeypatch):
+    """The launching process counts GPUs from the visibility lists (or the KFD topology), never through torch.cuda."""
+    import bench
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("torch.cuda called in the launcher")))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    n = bench.visible_gpus()
+    assert n is None or n >= 0
+
+
+def test_rank_cpu_slices_are_disjoint_and_equal():
+    import bench
+    cpus = list(range(3, 99))                        # 96 cores, not starting at 0
+    slices = [bench.rank_cpu_slice(cpus, r, 8) for r in range(8)]
+    assert all(len(s_) == 12 for s_ in slices)
+    assert sorted(sum(slices, [])) == cpus
+    assert bench.rank_cpu_slice(cpus, 0, 1) == cpus
+    assert bench.rank_cpu_slice([5, 7, 9], 1, 2) == [7]          # remainder unused: same count for every rank
+    assert bench.rank_cpu_slice([4], 3, 8) == [4]                # fewer cores than ranks: left alone
+
+
+_RANK_SCRIPT = """
+import os, sys, time
+r = int(os.environ["RANK"])
+open(os.path.join(sys.argv[1], "pid%d" % r), "w").write(str(os.getpid()))
+mode = sys.argv[2]
+if mode == "fail" and r == 1:
+    time.sleep(0.3)
+    sys.exit(3)
+if mode == "ok":
+    assert os.environ["WORLD_SIZE"] == "3" and os.environ["MARS_BENCH_STORE"]
+    sys.exit(0)
+time.sleep(120)
+"""
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    # a child that was reaped is gone; one that is a zombie of ours has been waited for by launch_ranks
+    try:
+        return open(f"/proc/{pid}/stat").read().split(")")[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_launch_ranks_stops_everyone_when_one_rank_dies(tmp_path):
+    """One rank exits with status 3 while the others would run for two minutes: the launcher returns 3 within
+    seconds and leaves no rank behind."""
+    import time
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(3, [str(tmp_path), "fail"], script=str(script), deadline_s=60)
+    assert rc == 3 and time.monotonic() - t0 < 15
+    pids = [int((tmp_path / f"pid{r}").read_text()) for r in range(3)]
+    assert not any(_alive(p) for p in pids)
+
+
+def test_launch_ranks_deadline_and_clean_exit(tmp_path):
+    import time
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    assert bench.launch_ranks(3, [str(tmp_path), "ok"], script=str(script), deadline_s=60) == 0
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(2, [str(tmp_path), "hang"], script=str(script), deadline_s=1.0)
+    assert rc == 124 and time.monotonic() - t0 < 15
+    assert not any(_alive(int((tmp_path / f"pid{r}").read_text())) for r in range(2))
