@@ -128,3 +128,46 @@ def test_product_simplex_rejects_non_finite_costs(pkg):
         assert np.isnan(lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), 30, 40))
     M = np.full((12, 9), np.nan)
     assert np.isnan(lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), 12, 9))
+
+
+def test_product_simplex_many_small_shapes(pkg):
+    """The basis tree is kept as a pre-order thread that is cut and re-strung at every pivot, with childless rows
+    kept out of it: small problems of every shape (either side the larger one, single rows and columns, ties)
+    walk through all of its corner cases.  Against the oracle's successive-shortest-path solver."""
+    lib = pkg.hip.lib()
+    rng = np.random.default_rng(99)
+    for trial in range(150):
+        n, m = int(rng.integers(1, 28)), int(rng.integers(1, 28))
+        M = rng.random((n, m))
+        if trial % 3 == 0:
+            M = np.round(M, 1)                        # many equal costs
+        if trial % 5 == 0:
+            M = np.abs(rng.normal(size=(n, 1)) - rng.normal(size=(1, m)))      # costs of points on a line
+        M = np.ascontiguousarray(M)
+        got = lib.marshost_emd2_uniform(ctypes.c_void_p(M.ctypes.data), n, m)
+        assert abs(got - emd2_uniform(M)) < 1e-10, (trial, n, m)
+
+
+def test_product_emd_scores_exact_pricing_switch():
+    """Entering arcs of the batch entry are selected by a single-precision scan; MARS_EMD_EXACT_PRICING=1 selects
+    them in double.  Both reach the same optimum (the scan only chooses among improving arcs)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from __graft_entry__ import load_package\n"
+        "ops = load_package(require_native=True).ops\n"
+        "rng = np.random.default_rng(4)\n"
+        "S = torch.from_numpy(rng.uniform(-1, 1, (120, 128)).astype(np.float32))\n"
+        "fg = torch.from_numpy((rng.random(120) < 0.7).astype(np.uint8))\n"
+        "bits = torch.from_numpy((rng.random((9, 100)) < 0.4).astype(np.uint8)); bits[:, 0] = 1\n"
+        "print(' '.join(repr(float(x)) for x in ops.emd_scores_host(S, fg, bits, threads=2)))\n" % root)
+    outs = []
+    for extra in ({}, {"MARS_EMD_EXACT_PRICING": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([float(x) for x in r.stdout.split()])
+    assert len(outs[0]) == 9 and max(abs(a - b) for a, b in zip(*outs)) < 1e-12
