@@ -888,7 +888,11 @@ __global__ __launch_bounds__(256) void flash_attn_mean_kernel(const __bf16* __re
 
 }  // namespace
 
-// MARS_FLASH_VARIANT=1 in the environment keeps the image towers on the plain tile loop (A/B runs)
+void mars_flash_attn32_launch(const void* qkv, void* O, float* lse, int B, int T, int H, float score_scale_log2, hipStream_t stream);
+
+// Image towers (no causal mask, more than three key tiles) run the 32x32x16 kernel of attention32.hip.  A/B runs:
+// MARS_FLASH_VARIANT=4 keeps them on flash_attn_pipe_kernel (16x16x32, one workgroup per query block), =2 the same
+// with class-token sequences tiled from key 0, =1 on the plain tile loop.
 static int flash_variant() {
     static const int v = [] { const char* e = getenv("MARS_FLASH_VARIANT"); return e ? atoi(e) : 0; }();
     return v;
@@ -909,6 +913,8 @@ extern "C" int marship_flash_attn(const void* qkv, void* O, float* lse, int B, i
     } else if (causal || flash_variant() == 1) {   // 32 queries per wave, 4 waves: 128 queries per workgroup
         dim3 grid((T + 127) / 128, B * H), block(256);
         hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, causal, score_scale_log2);
+    } else if (flash_variant() == 0 && T > 3 * KT) {   // image towers on the 32x32x16 matrix instruction (attention32.hip)
+        mars_flash_attn32_launch(qkv, O, lse, B, T, H, score_scale_log2, (hipStream_t)stream);
     } else {         // image towers: the same tiling with the pipelined tile loop
         dim3 grid((T + 127) / 128, B * H), block(256);
         if (T % KT == 1 && flash_variant() != 2)   // a class token in front of whole tiles of patches (MARS_FLASH_VARIANT=2: tiled from key 0)
