@@ -129,6 +129,11 @@ class MARS:
                 vta_g = self._text_prior_on_visual_grid(vta, vva.shape[0], dev)
             main.wait_stream(st["high"])
             main.wait_stream(st["vta"])
+            # results of the side streams that the caller's stream reads from here on: tell the allocator, so that a
+            # block freed meanwhile is not handed out again before this stream is done with it
+            for t_ in (vva, vta, vta_g):
+                if torch.is_tensor(t_) and t_.is_cuda:
+                    t_.record_stream(main)
             if handle is None:
                 fmm.start_solver(vva_mod.cost_matrix)
         else:

@@ -252,7 +252,9 @@ class FilteringMergingModule:
         prepared, self._prepared_text = getattr(self, "_prepared_text", None), None      # taken once, never reused
         if prepared is not None and prepared[0] == tuple(text):
             tfeat = prepared[1]
-            torch.cuda.current_stream(dev).wait_event(prepared[2])
+            here = torch.cuda.current_stream(dev)
+            here.wait_event(prepared[2])
+            tfeat.record_stream(here)       # made on the prompt stream, read here: its block is not reused before this stream got there
         else:
             tfeat = self._compute_alphaclip_text_feats(text)
         ops.cosine_scores(feats, tfeat, w["aclip"])

@@ -99,7 +99,9 @@ class VisualTextAlignmentModule:
         prepared, self._prepared = getattr(self, "_prepared", None), None        # taken once, never reused
         if prepared is not None and prepared[0] == fg_label:
             text = prepared[1]
-            torch.cuda.current_stream(self.device).wait_event(prepared[2])
+            here = torch.cuda.current_stream(self.device)
+            here.wait_event(prepared[2])
+            text.record_stream(here)        # made on the prompt stream, read here: its block is not reused before this stream got there
         else:
             text = self.compute_text_feats(fg_label)
         self.text_features = text           # kept alive until the next call (it may live on another stream's pool)

@@ -1,6 +1,7 @@
 """Whole ranking path on the GPU against the CPU oracle on the same seeded episode, and the
 size-independent properties that must hold at any configuration."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -170,3 +171,53 @@ def test_episode_on_a_gpu_that_is_not_current(pkg, cuda):
     rep = run_tiny_episode_parity(pkg, device="cuda:1", seed=3, dtype=torch.float32, tol=TOL)
     assert rep["order_equal"] and rep["mask_mismatch"] == 0, rep
     assert torch.cuda.current_device() == 0
+
+
+_NOCACHE_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from tests.helpers import tiny_config
+from __graft_entry__ import load_package
+from importlib import import_module
+pkg = load_package(require_native=True)
+MARS = import_module(pkg.__name__ + ".mars.MARS")
+cfg = tiny_config(pkg)
+dev = torch.device("cuda:0")
+mars = MARS.build_MARS_fss(cfg["args"], state_dicts=cfg["sds"])
+mars.concurrent = %(concurrent)r
+out = {}
+for e in (21, 22, 21):                        # two different episodes back to back, then the first again
+    ep = pkg.synth.make_episode(e, size=cfg["size"], nshot=cfg["nshot"], nprop=cfg["nprop"])
+    args = [ep[k].to(dev) for k in ("support_imgs", "support_masks", "query_img", "mask_proposals")]
+    pred = mars.predict(*args)
+    sc = mars.filtering_merging_component.scores()
+    out.setdefault(e, []).append(dict(pred=pred.cpu(), score=sc["score"], order=sc["order"], emd=sc["emd"], aclip=sc["aclip"],
+                                      vva=mars.vva.cpu(), vta=mars.vta.cpu()))
+    mars.clear()
+torch.save(out, %(path)r)
+"""
+
+
+def test_streams_without_the_caching_allocator(tmp_path):
+    """Side by side on four streams with the caching allocator OFF (every tensor that dies is freed at once and the
+    next allocation may get its address): two different episodes back to back, then the first again, give bit for
+    bit what the one-stream order gives, and the repeated episode gives what it gave the first time.  A result
+    read on a stream other than the one it was made on must therefore be kept alive by the hand-over itself."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in (True, False):
+        path = str(tmp_path / f"out_{int(mode)}.pt")
+        env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1", PYTORCH_NO_HIP_MEMORY_CACHING="1")
+        r = subprocess.run([sys.executable, "-c", _NOCACHE_SCRIPT % dict(root=root, concurrent=mode, path=path)], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        got[mode] = torch.load(path)
+    for e in (21, 22):
+        for i, (a, b) in enumerate(zip(got[True][e], got[False][e])):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (e, i, k)
+    first, again = got[True][21]
+    for k in first:
+        assert torch.equal(first[k], again[k]), k

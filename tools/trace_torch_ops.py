@@ -53,5 +53,10 @@ class Mode(TorchDispatchMode):
 with Mode():
     step()
 torch.cuda.synchronize()
-for (name, where), n in counts.most_common(60):
+VIEWS = ("view", "slice", "select.int", "aten.t.", "alias", "unsqueeze", "squeeze", "expand", "permute", "transpose", "reshape", "_unsafe_view",
+         "empty", "as_strided", "detach", "unbind", "split", "narrow")
+launching = [(k, n) for k, n in counts.most_common() if not any(v in k[0] for v in VIEWS)]
+print("operators that launch kernels or copies:", sum(n for _, n in launching), "calls;  views and allocations:",
+      sum(n for k, n in counts.items()) - sum(n for _, n in launching))
+for (name, where), n in launching:
     print(f"{n:5d}  {name:40s} {where}")
