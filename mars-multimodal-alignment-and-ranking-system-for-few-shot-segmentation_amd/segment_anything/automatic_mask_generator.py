@@ -11,6 +11,7 @@ the GPU).  Box NMS runs on the host.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -40,6 +41,12 @@ class SamAutomaticMaskGenerator:
         self.crop_n_points_downscale_factor, self.output_mode = crop_n_points_downscale_factor, output_mode
         self.predictor = SamPredictor(model)
         self.points_per_batch = points_per_batch
+        # Grid points per decoder launch chain.  The reference decodes the grid 64 points at a time (points_per_batch)
+        # to bound memory; every point's masks depend on that point alone, so the dense grid goes through the decoder
+        # in chunks of this many points (a multiple of points_per_batch: 1024 = the whole 32 x 32 grid), which costs one
+        # chain of launches and one host round trip per chunk instead of one per 64 points.  The caller's own prompts
+        # (select_point_coords) keep points_per_batch.
+        self.dense_points_per_launch = max(points_per_batch, int(os.environ.get("MARS_SAM_DENSE_CHUNK", "1024")) // points_per_batch * points_per_batch)
         self.pred_iou_thresh = pred_iou_thresh
         self.stability_score_thresh = stability_score_thresh
         self.stability_score_offset = stability_score_offset
@@ -141,8 +148,8 @@ class SamAutomaticMaskGenerator:
         lists = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
         if self.dense_pred:
             pts_all = self.point_grids[layer] * np.array([[cw, ch]], dtype=np.float64)
-            for b0 in range(0, len(pts_all), self.points_per_batch):
-                self._process_batch(pts_all[b0:b0 + self.points_per_batch], (ch, cw), lists)
+            for b0 in range(0, len(pts_all), self.dense_points_per_launch):
+                self._process_batch(pts_all[b0:b0 + self.dense_points_per_launch], (ch, cw), lists)
         if layer == 0 and select_point_coords is not None:
             assert select_point_labels is not None, "select_point_labels should not be None !"
             for coords, labels in zip(select_point_coords, select_point_labels):     # one array per prompt size
