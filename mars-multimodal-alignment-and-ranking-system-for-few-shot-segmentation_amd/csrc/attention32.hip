@@ -18,7 +18,9 @@
 // half-wave covers rows k0 .. k0+3 in four chunks: chunk c of row r at slot c ^ (((r >> 1) & 1) << 2), so that
 // rows two apart (same bank half) use the other four slots.
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "../../include/mars_hip.h"
 
@@ -88,17 +90,19 @@ __device__ __forceinline__ void attn_block(int id, int nbh, int nqb, int xcd_awa
 
 template <bool LEAD1>
 __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ O,
-                                                                  float* __restrict__ lse, int T, int H, float c2, int nbh, int xcd_aware) {
+                                                                  float* __restrict__ lse, int T, int H, float c2, int nbh, int xcd_aware,
+                                                                  unsigned* __restrict__ shared_count) {
     constexpr int NW = 4, QPB = NW * 32, PPW = 16 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KT * ROWB];     // [K|V][slot]: rings of three tiles
     __shared__ __attribute__((aligned(16))) unsigned char stage_q[NW][32 * ROWB];   // the next item's queries, a wave's 32 rows each
     __shared__ __attribute__((aligned(16))) unsigned char stage_kv[1024];           // its key 0 (bytes 0-127) and value 0 (128-255)
+    __shared__ __attribute__((aligned(32))) int xchg[8];   // after an item: [wave] whether the wave wants it worked again, [4] the item wave 0 took from the shared counter
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, hh = lane >> 5;
     const int D = H * 64;
 #ifdef MARS_STAMPS
-    unsigned long long st_compute = 0, st_wait = 0, st_top = 0, st_fin = 0, st_fill = 0;
+    unsigned long long st_compute = 0, st_wait = 0, st_top = 0, st_fin = 0, st_fill = 0, st_tail = 0, st_vote = 0, st_topwait = 0;
 #endif
     MARS_T(t_begin)
     const int64_t row_b = (int64_t)3 * D * 2;
@@ -251,90 +255,100 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
     // ---- the state of the item in hand (all wave-uniform) ----
     const unsigned char* base = nullptr;        // its image-head's qkv rows
     const unsigned char* nbase = nullptr;       // the next item's, or null
+    const unsigned char* fbase = nullptr;       // where fills beyond the item's last tile read: nbase, or base if there is no next item
     int qblk = 0, nqblk = 0;
     int g = 0;                                  // tiles this workgroup has been through: tile t of the item lives in ring slot (g + t) % 3
     bool wave_active = false;
 
-    // The tile loop is software pipelined: iteration t turns the scores of tile t (matrix results from the iteration
-    // before) into probabilities on the vector ALU while the matrix pipe works out the scores of tile t+1, then
-    // accumulates P(t) V(t).  At its top K(t+1) and V(t) are in LDS and their fragments are requested; the fills of
-    // K(t+2) (into the slot K(t) had: its fragments were read one iteration ago) and of V(t+1) (into the slot of
-    // V(t-1)) are started right behind and have the iteration to land - beyond the item's last tile they are the
-    // next item's tiles 0 and 1; one barrier per tile, at the bottom.
+    // The tile loop is software pipelined over three tiles: iteration t turns the scores of tile t (matrix results of
+    // the iteration before, in x) into probabilities e on the vector ALU while the matrix pipe first accumulates
+    // P(t-1) V(t-1) and then works out the scores of tile t+1 into x again; the probabilities are packed into p for
+    // the iteration after.  x is only ever written by the matrix pipe and e by the vector ALU, so no set of registers
+    // changes its role from one iteration to the next.  At the top K(t+1) and V(t-1) are in LDS and their fragments
+    // are requested; the fills of K(t+3) (into the slot K(t) had: its fragments were read one iteration ago) and of
+    // V(t+1) (into the slot of V(t-2)) are started right behind and have two iterations to land - beyond the item's
+    // last tile they are the next item's K tiles 0-2 and V tile 0; one barrier per tile, at the bottom.  The last
+    // product P(nt-1) V(nt-1) follows the loop.
     //
     // MODE 0: this wave only helps with fills and barriers.  MODE 1: absolute scale (reference 0); returns true if
     // some score exceeded the head room (the accumulators are then worthless and the workgroup runs the pass again
     // with the running maximum).  MODE 2: running maximum.
-    auto pass = [&](f32x16 (&sc)[2], auto mode_tag) -> bool {
+    auto pass = [&](f32x16 (&x)[2], auto mode_tag) -> bool {
         constexpr int MODE = decltype(mode_tag)::value;
-        // one iteration; LAST: tile nt-1 (the only one that can be ragged; no scores of a next tile)
-        auto iteration = [&](int t, auto last_tag) {
-            constexpr bool LAST = decltype(last_tag)::value;
+        f32x16 e[2];
+        bf16x8 p[2][2];
+        auto pv = [&]() {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(0, kb, u), p[kb][u], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(1, kb, u), p[kb][u], o[1], 0, 0, 0);
+                }
+        };
+        // one iteration; FIRST: tile 0 (no product of a tile before); LAST: tile nt-1 (the only one that can be
+        // ragged; no scores of a next tile)
+        auto iteration = [&](int t, auto first_tag, auto last_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
             MARS_T(t_top)
             if constexpr (MODE != 0) {
-                read_v((g + t) % 3);
+                if constexpr (!FIRST) read_v((g + t + 2) % 3);          // tile t-1
                 if constexpr (!LAST) read_k((g + t + 1) % 3);
             }
-            bool filled = false;
             {
-                const int tf = t + 3 - is_v;                    // K tile t+3 / V tile t+2
-                if (tf < nt) { fill_tile(base, tf, (g + tf) % 3); filled = true; }
-                else if (nbase) { fill_tile(nbase, tf - nt, (g + tf) % 3); filled = true; }
+                // (without a next item the tiles beyond the last are this item's first ones again: nobody reads
+                // them, and the loop stays free of branches)
+                const int tf = is_v ? t + 1 : t + 3;
+                const bool own = tf < nt;
+                fill_tile(own ? base : fbase, own ? tf : tf - nt, (g + tf) % 3);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (MODE != 0) {
                 // while the fragments are on their way: what needs the scores of tile t only
                 if constexpr (LAST) {
-                    if (ragged_last) mask_tail(sc, t);
+                    if (ragged_last) mask_tail(x, t);
                 }
-                float ref = 0.f;
+                float ref = 0.f, alpha = 1.f;
                 if constexpr (MODE == 2) {
-                    const float mnew = fmaxf(mrun, halves_max(tile_max(sc)));
-                    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                    const float mnew = fmaxf(mrun, halves_max(tile_max(x)));
+                    alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                    mrun = mnew;
+                    ref = mnew;
+                }
+#pragma unroll
+                for (int r = 0; r < EARLY; ++r) e[0][r] = __builtin_amdgcn_exp2f(MODE == 1 ? x[0][r] : x[0][r] - ref);
+                lds_wait();
+                // P(t-1) V(t-1), then the scores of tile t+1, on the matrix pipe ...
+                if constexpr (!FIRST) pv();
+                if constexpr (MODE == 2) {
                     if (!__all(alpha == 1.f)) {         // the running max moved for some query of this wave
                         o[0] *= alpha;
                         o[1] *= alpha;
                         lsum *= alpha;
                     }
-                    mrun = mnew;
-                    ref = mnew;
                 }
-#pragma unroll
-                for (int r = 0; r < EARLY; ++r) sc[0][r] = __builtin_amdgcn_exp2f(MODE == 1 ? sc[0][r] : sc[0][r] - ref);
-                lds_wait();
-                // the scores of tile t+1 on the matrix pipe ...
-                f32x16 sn[2];
-                if constexpr (!LAST) scores(sn);
                 // ... beside the probabilities of tile t on the vector ALU
-                bf16x8 p[2][2];
-                float a0, a1, a2, a3;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                    for (int r = (kb == 0 ? EARLY : 0); r < 16; ++r) sc[kb][r] = __builtin_amdgcn_exp2f(MODE == 1 ? sc[kb][r] : sc[kb][r] - ref);
-                    if (kb == 0) { a0 = sc[0][0]; a1 = sc[0][1]; a2 = sc[0][2]; a3 = sc[0][3]; }
-#pragma unroll
-                    for (int r = (kb == 0 ? 4 : 0); r < 16; r += 4) { a0 += sc[kb][r]; a1 += sc[kb][r + 1]; a2 += sc[kb][r + 2]; a3 += sc[kb][r + 3]; }
-                    p[kb][0] = pack8(sc[kb], 0);
-                    p[kb][1] = pack8(sc[kb], 1);
-                }
-                lsum += (a0 + a1) + (a2 + a3);
-                // P(t) V(t)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(0, kb, u), p[kb][u], o[0], 0, 0, 0);
-                        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(1, kb, u), p[kb][u], o[1], 0, 0, 0);
-                    }
-                if constexpr (!LAST) { sc[0] = sn[0]; sc[1] = sn[1]; }
+                    for (int r = (kb == 0 ? EARLY : 0); r < 16; ++r) e[kb][r] = __builtin_amdgcn_exp2f(MODE == 1 ? x[kb][r] : x[kb][r] - ref);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!LAST) scores(x);
+                float a0 = e[0][0], a1 = e[0][1], a2 = e[0][2], a3 = e[0][3];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int r = (kb == 0 ? 4 : 0); r < 16; r += 4) { a0 += e[kb][r]; a1 += e[kb][r + 1]; a2 += e[kb][r + 2]; a3 += e[kb][r + 3]; }
+                    p[kb][0] = pack8(e[kb], 0);
+                    p[kb][1] = pack8(e[kb], 1);
+                }
+                lsum += (a0 + a1) + (a2 + a3);
             }
             MARS_T(t_work)
             // the fills started one iteration ago have landed (this iteration's four stay in flight); vector memory
             // operations retire in order, so everything older - the staged queries, the last item's stores - has too
             __builtin_amdgcn_sched_barrier(0);
-            if (filled) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             MARS_T(t_landed)
             meet();
             MARS_T(t_met)
@@ -342,8 +356,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
             MARS_ACC(st_wait, t_work, t_met)
             MARS_ACC(st_fill, t_work, t_landed)
         };
-        for (int t = 0; t + 1 < nt; ++t) iteration(t, std::false_type{});
-        iteration(nt - 1, std::true_type{});
+        iteration(0, std::true_type{}, std::false_type{});
+        for (int t = 1; t + 1 < nt; ++t) iteration(t, std::false_type{}, std::false_type{});
+        iteration(nt - 1, std::false_type{}, std::true_type{});
+        MARS_T(t_tail)
+        if constexpr (MODE != 0) {
+            read_v((g + nt - 1) % 3);
+            lds_wait();
+            pv();
+        }
+        MARS_T(t_tailed)
+        MARS_ACC(st_tail, t_tail, t_tailed)
         // absolute scale: a probability beyond 2^HEAD_ROOM shows in its row's sum (no maxima are taken on the way)
         return MODE == 1 && __any(!(halves_sum(lsum) < SUM_LIMIT));
     };
@@ -404,20 +427,35 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
         }
     };
 
-    // the first item's queries (and key / value 0) and its first tiles: K(0), V(0), K(1)
-    int id = blockIdx.x;
+    // Which items a workgroup works on.  Its first two are blockIdx.x and blockIdx.x + gridDim.x.  With a shared
+    // counter (shared_count: one word per XCD, then the count of finished workgroups) the later ones are taken from
+    // the counter of the workgroup's XCD as it goes, two to three items ahead of the one it works on; without, they follow
+    // at a stride of gridDim.x.  Why not the fixed stride alone: of the two workgroups of a CU the one dispatched
+    // first wins the issue arbitration (oldest first) and runs about a quarter faster; with equal shares it ends
+    // early and the other one finishes alone, with nobody to fill the matrix pipe while it waits.
+    const int grid = (int)gridDim.x, xcd = blockIdx.x & 7;
+    int id = blockIdx.x, nid = min(id + grid, nitems), taking = nitems;
+    auto take = [&]() -> unsigned { return __hip_atomic_fetch_add(shared_count + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // the workgroup's third, fourth ... item from the counter's answers 0, 1, ... (the static ones of all workgroups come first)
+    auto next_item = [&](unsigned j) -> int { return (int)min((2u * (unsigned)(grid >> 3) + j) * 8u + (unsigned)xcd, (unsigned)nitems); };
+    unsigned took = 0;                          // (thread 0) what the counter said; looked at when an item is done
+    if (shared_count && tid == 0 && nid < nitems) took = take();
+    // the first item's queries (and key / value 0) and its first tiles: K(0), K(1), K(2) and V(0)
     base = item_base(id, qblk);
     stage_item(base, qblk);
     fill_tile(base, 0, 0);
-    fill_tile(base, 1, 1);
-    if (!is_v) fill_tile(base, 2, 2);
+    if (!is_v) {
+        fill_tile(base, 1, 1);
+        fill_tile(base, 2, 2);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (; id < nitems; id += (int)gridDim.x) {
+    while (id < nitems) {
         MARS_T(t_item)
-        const int nid = id + (int)gridDim.x;
+        if (!shared_count) taking = min(nid + grid, nitems);
         nbase = nid < nitems ? item_base(nid, nqblk) : nullptr;
+        fbase = nbase ? nbase : base;
         const int q0 = qblk * QPB + wave * 32;
         wave_active = q0 < T;                   // trailing waves of an image-head's last block only help with the fills
         // the item's queries, key 0 and value 0 from where the last item (or the lines above) had them brought, and
@@ -449,7 +487,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
         }
         if (wave_active) read_k(g % 3);
         lds_wait();
+        MARS_T(t_topmeet)
         meet();                                 // everybody has its queries: the staging area is free for the next item
+        MARS_T(t_topmet)
+        MARS_ACC(st_topwait, t_item, t_topmet)
         __builtin_amdgcn_sched_barrier(0);
         if (nbase) stage_item(nbase, nqblk);
         __builtin_amdgcn_sched_barrier(0);
@@ -463,7 +504,36 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
         if (!wave_active) again = pass(sc, std::integral_constant<int, 0>{});
         else if (lazy) again = pass(sc, std::integral_constant<int, 1>{});
         else again = pass(sc, std::integral_constant<int, 2>{});
-        if (__syncthreads_or(again)) {
+        MARS_T(t_voting)
+        // The waves tell each other whether one of them wants the item worked again, and wave 0 tells the item it
+        // took, through LDS and one barrier (asm accesses, and no drain of the fills in flight: see the LDS reads).
+        bool redo;
+        {
+            const unsigned xa = (unsigned)(uintptr_t)(lds_ptr_t)&xchg[0];
+            int mine = again ? 1 : 0;
+            if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(xa + 4 * wave), "v"(mine) : "memory");
+            int mine_next = nitems;
+            if (shared_count && tid == 0) {
+                asm volatile("" : "+v"(took));  // (nothing derived from the counter's answer before this point: it has had the item to arrive)
+                if (nid < nitems) mine_next = next_item(took);
+                asm volatile("ds_write_b32 %0, %1 offset:16" :: "v"(xa), "v"(mine_next) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            meet();
+            // the item after that one: asked for now (the fills in flight are old enough for a wait to cost little,
+            // should the compiler want one around the request), looked at when the next item is done
+            if (shared_count && tid == 0 && mine_next < nitems) took = take();
+            v4i32 all;
+            int got;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(all) : "v"(xa));
+            asm volatile("ds_read_b32 %0, %1 offset:16" : "=v"(got) : "v"(xa));
+            lds_wait();
+            redo = __builtin_amdgcn_readfirstlane(all[0] | all[1] | all[2] | all[3]) != 0;
+            if (shared_count) taking = __builtin_amdgcn_readfirstlane(got);
+        }
+        MARS_T(t_voted)
+        MARS_ACC(st_vote, t_voting, t_voted)
+        if (redo) {
             // some wave's scores left the absolute scale's range: those waves start over with the running maximum,
             // the others help with the fills again.  The ring is set up afresh (the pass has left the next item's
             // first tiles in it; the second pass brings them again), key 0 and value 0 come straight from memory.
@@ -478,8 +548,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the fills the first pass left in flight
             __syncthreads();
             fill_tile(base, 0, g % 3);
-            fill_tile(base, 1, (g + 1) % 3);
-            if (!is_v) fill_tile(base, 2, (g + 2) % 3);
+            if (!is_v) {
+                fill_tile(base, 1, (g + 1) % 3);
+                fill_tile(base, 2, (g + 2) % 3);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (wave_active) read_k(g % 3);
@@ -518,15 +590,62 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
         g += nt;
         base = nbase;
         qblk = nqblk;
+        id = nid;
+        nid = taking;
     }
+    // the last workgroup to finish leaves the counters as it found them: zero
+    if (shared_count && tid == 0) {
+        const unsigned done = __hip_atomic_fetch_add(shared_count + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned)grid - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(shared_count + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup gives its LDS back
 #ifdef MARS_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MARS_T(t_end)
     if (lane == 0) {
-        unsigned long long* sb = mars_attn32_stamps + ((size_t)blockIdx.x * NW + wave) * 8;
-        sb[0] = st_top; sb[1] = st_compute; sb[2] = st_wait; sb[3] = st_fin; sb[4] = t_end - t_begin; sb[5] = 1; sb[6] = st_fill;
+        unsigned long long* sb = mars_attn32_stamps + ((size_t)blockIdx.x * NW + wave) * 16;
+        sb[0] = st_top; sb[1] = st_compute; sb[2] = st_wait; sb[3] = st_fin; sb[4] = t_end - t_begin; sb[5] = st_tail; sb[6] = st_fill; sb[7] = st_vote; sb[8] = st_topwait;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        sb[9] = hw; sb[10] = xcc; sb[11] = t_begin; sb[12] = t_end;
     }
 #endif
+}
+
+// Item counters of the launches.  Launches on one stream run one after the other and each leaves its counters at
+// zero, so a stream keeps one set for good; launches on different streams may overlap and get different sets.  The
+// sets live in a file-scope device array (no allocation); a process that uses more than MAX_STREAM_SETS streams on
+// a device gets no counters for the further ones (those launches walk their items at a fixed stride).
+constexpr int MAX_STREAM_SETS = 64, MAX_DEVICES = 16;
+__device__ __attribute__((aligned(256))) unsigned item_counters[MAX_STREAM_SETS][16];
+
+unsigned* stream_counters(hipStream_t stream) {
+    struct PerDevice { unsigned* sets = nullptr; bool failed = false; std::vector<hipStream_t> streams; };
+    static std::mutex mu;
+    static PerDevice devices[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> hold(mu);
+    PerDevice& d = devices[dev];
+    if (d.failed) return nullptr;
+    if (!d.sets) {
+        // each device has a copy of the array at an address of its own (zero when the code object is loaded)
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(item_counters)) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            d.failed = true;
+            return nullptr;
+        }
+        d.sets = (unsigned*)p;
+    }
+    for (size_t i = 0; i < d.streams.size(); ++i)
+        if (d.streams[i] == stream) return d.sets + 16 * i;
+    if ((int)d.streams.size() >= MAX_STREAM_SETS) return nullptr;
+    d.streams.push_back(stream);
+    return d.sets + 16 * (d.streams.size() - 1);
 }
 
 }  // namespace
@@ -539,10 +658,15 @@ void mars_flash_attn32_launch(const void* qkv, void* O, float* lse, int B, int T
     const int items = ((T + 127) / 128) * B * H;
     static const int persist = [] { const char* e = getenv("MARS_FLASH32_PERSIST"); return e ? atoi(e) : 1; }();
     static const int xcd_aware = [] { const char* e = getenv("MARS_FLASH_XCD"); return e ? atoi(e) : 1; }();
+    static const int shared = [] { const char* e = getenv("MARS_FLASH32_SHARED"); return e ? atoi(e) : 1; }();
     int slots = cus * 2;
     slots -= slots % 8;
-    dim3 grid(persist && items > slots && slots > 0 ? slots : items), block(256);
+    const bool walking = persist && items > slots && slots > 0;
+    dim3 grid(walking ? slots : items), block(256);
     const int nbh = B * H;
-    if (T % KT == 1) hipLaunchKernelGGL(flash_attn_w32_kernel<true>, grid, block, 0, stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, score_scale_log2, nbh, xcd_aware);
-    else hipLaunchKernelGGL(flash_attn_w32_kernel<false>, grid, block, 0, stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, score_scale_log2, nbh, xcd_aware);
+    // a workgroup's third and later items come from counters shared by the launch (if it has that many, and if this
+    // stream could be given a set of counters)
+    unsigned* counters = walking && shared && items > 2 * slots ? stream_counters(stream) : nullptr;
+    if (T % KT == 1) hipLaunchKernelGGL(flash_attn_w32_kernel<true>, grid, block, 0, stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, score_scale_log2, nbh, xcd_aware, counters);
+    else hipLaunchKernelGGL(flash_attn_w32_kernel<false>, grid, block, 0, stream, (const __bf16*)qkv, (__bf16*)O, lse, T, H, score_scale_log2, nbh, xcd_aware, counters);
 }
