@@ -12,7 +12,8 @@
  *     the 2 MiB static array of marship_vva_prior_static
  *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), no sync; the stream and
  *     every device pointer must belong to the device that is current in the calling thread
- *   - no state besides the two GEMM tuning hooks (process-wide relaxed atomics; see their comments)
+ *   - no state besides the three GEMM tuning hooks (variant, split, slots: process-wide relaxed atomics; see their
+ *     comments) and the device-resident counters and scratch arrays named at their entry points
  *   - return 0 on success, negative on error; marship_last_error() gives the text
  *   - "TN GEMM": C[M,N] = A[M,K] * B[N,K]^T, both operands K-contiguous
  *   - dtype codes: 0 = float32, 1 = bfloat16
@@ -99,10 +100,15 @@ int marship_layernorm(const float* x, int64_t x_stride, const float* w, const fl
  * side of it, see MarsGemm.ln_*: marship_ln_finish turns the row sums a stream product left in ln_part
  * ([rows, nparts, 2], nparts = N/64) into stat [rows, 2] = mean, 1/sqrt(var + eps) (var = E[x^2] - mean^2 in
  * f32); marship_row_stats computes the same statistics and the two bf16 planes straight from f32 rows, for the
- * first LayerNorm of a chain (copy = bf16(x), lo = bf16(x - copy), both [rows, D] with row stride ldcopy). */
-int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, void* stream);
+ * first LayerNorm of a chain (copy = bf16(x), lo = bf16(x - copy), both [rows, D] with row stride ldcopy).
+ * The folded form rounds x, not x - mean, to bf16: against a LayerNorm of the f32 rows it loses a factor of about
+ * |mean| * rstd in accuracy on a row whose mean is large against its spread.  `watch` (may be null): one f32 that
+ * both calls raise to the largest |mean| * rstd above `watch_limit` they meet (an atomic maximum; the caller zeroes
+ * it and reads it when the stream has passed), for callers that want to fall back to stand-alone LayerNorms then. */
+int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, float* watch,
+                      float watch_limit, void* stream);
 int marship_row_stats(const float* x, int64_t x_stride, int rows, int D, float eps, void* copy, void* lo,
-                      int64_t ldcopy, float* stat, void* stream);
+                      int64_t ldcopy, float* stat, float* watch, float watch_limit, void* stream);
 /* Patch extraction for the strided conv patch embeddings (patch_embed.py:76; clip/model.py:361;
  * alpha_clip/model.py:359-361) with the input normalisation (x*prescale - mean[c])/std[c] fused
  * (backbone_loader.py:74-78,178-179,185).  img [B,C,H,W] (f32, or u8 when in_u8), out
@@ -111,6 +117,11 @@ int marship_row_stats(const float* x, int64_t x_stride, int rows, int D, float e
 int marship_im2col(const void* img, int in_u8, int B, int C, int H, int W, int p, const float* mean,
                    const float* stdv, float prescale, void* out, int64_t ldo, int col_off,
                    int out_dtype, void* stream);
+/* Text tokens: X[n*L + l, :] = table[ids[n*L + l], :] + pos[l, :]  (clip/model.py:488-489: token_embedding(text) +
+ * positional_embedding).  table f32 [vocab, D], ids int32 [rows] (rows = n*L; an id outside the table is clamped
+ * into it), pos f32 [L, D], X f32 [rows, D]. */
+int marship_embed_tokens(const float* table, int vocab, const int32_t* ids, const float* pos, float* X,
+                         int64_t rows, int L, int D, void* stream);
 /* Token rows that do not come from the patch GEMM: cls(+pos[0]) and register tokens
  * (vision_transformer.py:230-241; clip/model.py:364-365). X f32 [B,T,D]. */
 int marship_write_prefix_tokens(float* X, int B, int T, int D, const float* cls, const float* pos0,

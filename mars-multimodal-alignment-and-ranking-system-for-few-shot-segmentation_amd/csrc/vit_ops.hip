@@ -92,8 +92,16 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 // ---------------------------------------------------------------- LayerNorm folded into the products around it
 // mean and rstd of every row from the sums the producing epilogue left per run of 64 columns; sixteen lanes
 // share a row (one 128-byte line of sums per request when a row has sixteen runs) and add in a fixed order
+// `watch` (optional): rows whose mean is large against their spread, |mean| * rstd > watch_limit, leave the largest
+// such ratio there (the bit pattern of a non-negative float orders like an unsigned): the products that read the
+// stream's bf16 copy lose that factor in accuracy against a LayerNorm of the f32 rows, and a caller may want to know.
+__device__ __forceinline__ void watch_ratio(float* watch, float limit, float mean, float rstd) {
+    const float ratio = fabsf(mean) * rstd;
+    if (watch && ratio > limit) atomicMax((unsigned*)watch, __float_as_uint(ratio));
+}
+
 __global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict__ part, int nparts, int rows, int D, float eps,
-                                                        float* __restrict__ stat) {
+                                                        float* __restrict__ stat, float* __restrict__ watch, float watch_limit) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l16 = threadIdx.x & 15;
     const bool live = row < rows;
     const float2* p = (const float2*)(part + (int64_t)(live ? row : 0) * nparts * 2);
@@ -111,7 +119,9 @@ __global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict_
     if (live && l16 == 0) {
         const float mean = s / (float)D;
         const float var = fmaxf(q / (float)D - mean * mean, 0.f);
-        *(float2*)(stat + 2 * (int64_t)row) = make_float2(mean, 1.0f / sqrtf(var + eps));
+        const float rstd = 1.0f / sqrtf(var + eps);
+        *(float2*)(stat + 2 * (int64_t)row) = make_float2(mean, rstd);
+        watch_ratio(watch, watch_limit, mean, rstd);
     }
 }
 
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict_
 template <int NCH>
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t xs, int rows, int D, float eps,
                                                         __bf16* __restrict__ copy, __bf16* __restrict__ lo, int64_t ldcopy,
-                                                        float* __restrict__ stat) {
+                                                        float* __restrict__ stat, float* __restrict__ watch, float watch_limit) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -151,7 +161,9 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     if (lane == 0) {
         const float mean = s / (float)D;
         const float var = fmaxf(q / (float)D - mean * mean, 0.f);
-        *(float2*)(stat + 2 * (int64_t)row) = make_float2(mean, 1.0f / sqrtf(var + eps));
+        const float rstd = 1.0f / sqrtf(var + eps);
+        *(float2*)(stat + 2 * (int64_t)row) = make_float2(mean, rstd);
+        watch_ratio(watch, watch_limit, mean, rstd);
     }
 }
 
@@ -190,6 +202,21 @@ __global__ void prefix_tokens_kernel(float* X, int B, int T, int D, const float*
         else v = regs[(int64_t)(r - 1) * D + d];
         X[((int64_t)b * T + r) * D + d] = v;
     }
+}
+
+// ---------------------------------------------------------------- token embedding
+// X[(n*L + l), :] = table[ids[n*L + l], :] + pos[l, :]; a wave per row
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restrict__ table, int vocab, const int32_t* __restrict__ ids,
+                                                           const float* __restrict__ pos, float* __restrict__ X, int64_t rows, int L, int D) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);       // (the caller checks the ids; a bad one must not read outside the table)
+    const float* t = table + (int64_t)id * D;
+    const float* p = pos + (int64_t)(r % L) * D;
+    float* x = X + r * D;
+    for (int c = lane; c < D; c += 64) x[c] = t[c] + p[c];
 }
 
 // ---------------------------------------------------------------- transpose (32x32 tiles through LDS)
@@ -347,22 +374,25 @@ extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* 
     return 0;
 }
 
-extern "C" int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, void* stream) {
+extern "C" int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, float* watch,
+                                 float watch_limit, void* stream) {
     MARS_CHECK(part && stat && rows > 0 && nparts > 0 && D > 0, "ln_finish: bad arguments");
-    MARS_CHECK((uintptr_t)part % 8 == 0 && (uintptr_t)stat % 8 == 0, "ln_finish: pointers must be 8-byte aligned");
-    hipLaunchKernelGGL(ln_finish_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nparts, rows, D, eps, stat);
+    MARS_CHECK((uintptr_t)part % 8 == 0 && (uintptr_t)stat % 8 == 0 && (uintptr_t)watch % 4 == 0, "ln_finish: pointers must be 8-byte aligned (watch: 4)");
+    MARS_CHECK(!watch || watch_limit >= 0.f, "ln_finish: watch_limit must not be negative");
+    hipLaunchKernelGGL(ln_finish_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nparts, rows, D, eps, stat, watch, watch_limit);
     MARS_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int marship_row_stats(const float* x, int64_t x_stride, int rows, int D, float eps, void* copy, void* lo,
-                                 int64_t ldcopy, float* stat, void* stream) {
+                                 int64_t ldcopy, float* stat, float* watch, float watch_limit, void* stream) {
     MARS_CHECK(x && copy && lo && stat && rows > 0, "row_stats: bad arguments");
+    MARS_CHECK((uintptr_t)watch % 4 == 0 && (!watch || watch_limit >= 0.f), "row_stats: watch");
     MARS_CHECK(D > 0 && D <= 2048 && D % 4 == 0 && x_stride % 4 == 0 && ldcopy % 4 == 0 && ldcopy >= D, "row_stats: D=%d / strides not supported", D);
     MARS_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)copy % 8 == 0 && (uintptr_t)lo % 8 == 0 && (uintptr_t)stat % 8 == 0, "row_stats: alignment");
     dim3 grid((rows + 3) / 4), block(256);
     const int nch = (D / 4 + 63) / 64;
-#define MARS_RS(N) hipLaunchKernelGGL((row_stats_kernel<N>), grid, block, 0, (hipStream_t)stream, x, x_stride, rows, D, eps, (__bf16*)copy, (__bf16*)lo, ldcopy, stat);
+#define MARS_RS(N) hipLaunchKernelGGL((row_stats_kernel<N>), grid, block, 0, (hipStream_t)stream, x, x_stride, rows, D, eps, (__bf16*)copy, (__bf16*)lo, ldcopy, stat, watch, watch_limit);
     if (nch <= 2) { MARS_RS(2) } else if (nch <= 4) { MARS_RS(4) } else { MARS_RS(8) }
 #undef MARS_RS
     MARS_LAUNCH_CHECK();
@@ -397,6 +427,15 @@ extern "C" int marship_write_prefix_tokens(float* X, int B, int T, int D, const 
     MARS_CHECK(T >= 1 + num_regs, "prefix_tokens: T too small");
     hipLaunchKernelGGL(prefix_tokens_kernel, dim3(grid_for((int64_t)B * (1 + num_regs) * D)), dim3(256), 0, (hipStream_t)stream,
                        X, B, T, D, cls, pos0, regs, num_regs);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_embed_tokens(const float* table, int vocab, const int32_t* ids, const float* pos, float* X, int64_t rows,
+                                    int L, int D, void* stream) {
+    MARS_CHECK(table && ids && pos && X, "embed_tokens: null pointer");
+    MARS_CHECK(vocab > 0 && rows > 0 && L > 0 && D > 0 && rows % L == 0, "embed_tokens: bad shape rows=%lld L=%d D=%d", (long long)rows, L, D);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, vocab, ids, pos, X, rows, L, D);
     MARS_LAUNCH_CHECK();
     return 0;
 }

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 import os
+import warnings
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -187,14 +188,16 @@ class Tower:
         return P
 
 
-def _blocks_forward_folded(self, x: torch.Tensor, blocks: List[Block], on_block=None) -> None:
+def _blocks_forward_folded(self, x: torch.Tensor, blocks: List[Block], on_block=None, watch=None) -> None:
     """``block_forward`` over a run of blocks built with ``fold=True``: no LayerNorm pass reads the stream.
     ``on_block(i)`` is called when block i has been queued (a caller with work for other streams can issue it
     between the blocks instead of behind all of them).
     Inside the run the f32 stream lives in two bf16 planes, hi = bf16(x) and lo = bf16(x - hi).  The products
     that add to it (attention projection, second MLP layer) read and write the planes and leave the row sums;
     the products that would have read normalised rows (qkv, first MLP layer) take the hi plane and apply mean
-    and rstd to their accumulators.  x f32 [B,T,D], updated in place (written by the last product of the run)."""
+    and rstd to their accumulators.  x f32 [B,T,D], updated in place (written by the last product of the run).
+    ``watch`` = (f32 [1] on the device, limit): raised to the largest |mean| * rstd above the limit that a row of
+    the stream shows at any LayerNorm of the run (the accuracy the folded form gives up on that row)."""
     B, T, D = x.shape
     M = B * T
     w = self.ws(B, T, blocks[0].hidden_alloc)
@@ -206,17 +209,18 @@ def _blocks_forward_folded(self, x: torch.Tensor, blocks: List[Block], on_block=
                              stat=torch.zeros(M, 2, dtype=torch.float32, device=self.device))
     hi, lo, part, stat = f["hi"], f["lo"], f["part"], f["stat"]
     x2 = x.view(M, D)
-    ops.row_stats(x2, blocks[0].ln1.eps, hi, lo, stat)
+    wt, wl = watch if watch is not None else (None, 0.0)
+    ops.row_stats(x2, blocks[0].ln1.eps, hi, lo, stat, wt, wl)
     for i, blk in enumerate(blocks):
         assert blk.folded
         ops.linear(hi, blk.qkv.w, w["qkv"], bias=blk.qkv.b, gamma=self.query_scale(False), ln_in=(stat, blk.qkv_colsum))
         self.attention(w, B, T, causal=False, need_probs=False)
         ops.linear(w["ao"], blk.proj.w, x2, bias=blk.proj.b, gamma=blk.ls1, ln_out=(hi, lo, part))
-        ops.ln_finish(part, M, D, blk.ln2.eps, stat)
+        ops.ln_finish(part, M, D, blk.ln2.eps, stat, wt, wl)
         ops.linear(hi, blk.fc1.w, w["hid"], bias=blk.fc1.b, act=blk.act, ln_in=(stat, blk.fc1_colsum))
         if i + 1 < len(blocks):
             ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, ln_out=(hi, lo, part))
-            ops.ln_finish(part, M, D, blocks[i + 1].ln1.eps, stat)
+            ops.ln_finish(part, M, D, blocks[i + 1].ln1.eps, stat, wt, wl)
         else:
             ops.linear(w["hid"], blk.fc2.w, x2, bias=blk.fc2.b, gamma=blk.ls2, ln_out=(hi, lo, None))
         if on_block is not None:
@@ -279,6 +283,7 @@ def _make_block(sd: SD, names: dict, D: int, device, dtype, eps: float, act: int
     b.ln1 = Norm(sd, names["ln1"], device, eps)
     b.ln2 = Norm(sd, names["ln2"], device, eps)
     b.folded = fold
+    b.names = names
     if fold:
         assert ffn == "mlp" and dtype == torch.bfloat16
         b.qkv = Lin(*_fold_norm(sd[names["qkv_w"]], sd[names["qkv_b"]], sd[names["ln1"] + ".weight"], sd[names["ln1"] + ".bias"]), dtype, device)
@@ -421,14 +426,17 @@ class _TextTower:
         """encode_text (clip/model.py:486-499): causal transformer, EOT feature, text_projection."""
         tokens_cpu = tokens.cpu()
         n, L = tokens_cpu.shape
-        idx = ops.upload_small(tokens_cpu.long(), self.device)      # queued, not waited for (ops._PinnedRing)
-        X = (self.tok.index_select(0, idx.reshape(-1)).view(n, L, -1) + self.pos).contiguous()  # embedding gather
+        assert int(tokens_cpu.min()) >= 0 and int(tokens_cpu.max()) < self.tok.shape[0], "token id outside the vocabulary"
+        idx = ops.upload_small(tokens_cpu.int().contiguous(), self.device)      # queued, not waited for (ops._PinnedRing)
+        X = torch.empty(n, L, self.tok.shape[1], dtype=torch.float32, device=self.device)
+        ops.embed_tokens(self.tok, idx, self.pos[:L].contiguous(), X)           # token_embedding(text) + positional_embedding
         for blk in self.tower.blocks:
             self.tower.block_forward(X, blk, causal=True)
         eot = tokens_cpu.argmax(dim=-1)
-        rows = ops.upload_small(torch.arange(n) * L + eot, self.device)
+        rows = ops.upload_small((torch.arange(n) * L + eot).int().contiguous(), self.device)
         W = self.cfg.transformer_width
-        sel = X.view(n * L, W).index_select(0, rows).contiguous()
+        sel = torch.empty(n, W, dtype=torch.float32, device=self.device)
+        ops.gather_rows(X.view(n * L, W), rows, sel)
         y = torch.empty(n, W, dtype=torch.float32, device=self.device)
         ops.layernorm(sel, self.ln_final.w, self.ln_final.b, y, self.ln_final.eps)
         out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
@@ -664,8 +672,47 @@ class AlphaCLIP(_TextTower):
         self.ln_post = Norm(sd, "visual.ln_post", device, 1e-5)
         self.vproj_t = Lin(sd["visual.proj"].t().contiguous(), None, torch.float32, device)  # [E, W]
         self.first_token_last_block = os.environ.get("MARS_FULL_LAST_BLOCK", "0") != "1"
+        # The folded LayerNorms give up a factor |mean| / std of accuracy on a row whose mean is large against its
+        # spread (they round x, not x - mean, to bf16).  Every folded run leaves the largest such factor above this
+        # limit it met; the next call looks at it and, if there is one, goes back to stand-alone LayerNorms for
+        # the rest of the process (MARS_FOLD_LN_LIMIT, default 8; 0 or less: do not look).
+        self._sd = sd                       # (a reference, for _unfold)
+        self.fold_limit = float(os.environ.get("MARS_FOLD_LN_LIMIT", "8"))
+        self._fold_watch: Optional[dict] = None
         self._bufs: Dict[int, dict] = {}
         self.input_resolution = cfg.image_resolution
+
+    def _fold_now(self) -> bool:
+        """Whether this call folds its LayerNorms: looks at what the folded runs so far have reported."""
+        if not self.fold_ln:
+            return False
+        if self.fold_limit <= 0 or self.device.type != "cuda":
+            return True
+        wt = self._fold_watch
+        if wt is None:
+            wt = self._fold_watch = dict(dev=torch.zeros(1, dtype=torch.float32, device=self.device),
+                                         host=torch.zeros(1, dtype=torch.float32).pin_memory(),
+                                         event=torch.cuda.Event(), pending=False)
+        if wt["pending"] and wt["event"].query():
+            wt["pending"] = False
+            worst = float(wt["host"][0])
+            if worst > 0.0:
+                warnings.warn(f"AlphaCLIP: a row of the residual stream has |mean| / std = {worst:.1f} (limit {self.fold_limit:g}); "
+                              "the LayerNorms run stand-alone from here on (MARS_FOLD_LN_LIMIT)")
+                self._unfold()
+        return self.fold_ln
+
+    def _unfold(self) -> None:
+        """The blocks built with folded LayerNorms get the plain weights of their qkv and fc1 products back (from the
+        state dict the model was built from) and run through ``Tower.block_forward`` from here on."""
+        sd = self._sd
+        for b in self.vtower.blocks:
+            if b.folded:
+                n = b.names
+                b.qkv = Lin(sd[n["qkv_w"]], sd[n["qkv_b"]], self.dtype, self.device)
+                b.fc1 = Lin(sd[n["fc1"] + ".weight"], sd[n["fc1"] + ".bias"], self.dtype, self.device)
+                b.folded = False
+        self.fold_ln = False
 
     def visual(self, image: torch.Tensor, alpha: torch.Tensor, image_u8: bool = False, mean=None, std=None, on_block=None) -> torch.Tensor:
         """model.visual(image, alpha) (alpha_clip/model.py:358-386).  ``image`` is [n,3,R,R] or [1,3,R,R]
@@ -711,8 +758,14 @@ class AlphaCLIP(_TextTower):
         ops.write_prefix_tokens(X, self.class_embedding, self.vpos[0], None)
         X2 = X.view(n * T, D)
         ops.layernorm(X2, self.ln_pre.w, self.ln_pre.b, X2, self.ln_pre.eps)
-        if self.fold_ln and len(self.vtower.blocks) > 1:
-            self.vtower.blocks_forward_folded(X, self.vtower.blocks[:-1], on_block=on_block)
+        if self._fold_now() and len(self.vtower.blocks) > 1:
+            wt = self._fold_watch
+            self.vtower.blocks_forward_folded(X, self.vtower.blocks[:-1], on_block=on_block,
+                                              watch=(wt["dev"], self.fold_limit) if wt is not None else None)
+            if wt is not None:              # its value travels to the host behind the run; nobody waits for it here
+                wt["host"].copy_(wt["dev"], non_blocking=True)
+                wt["event"].record()
+                wt["pending"] = True
         else:
             for i, blk in enumerate(self.vtower.blocks[:-1]):
                 self.vtower.block_forward(X, blk)

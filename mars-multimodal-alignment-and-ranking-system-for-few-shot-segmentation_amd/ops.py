@@ -210,15 +210,19 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, ac
          ln_out=ln_out, ln_in=ln_in)
 
 
-def ln_finish(part: torch.Tensor, rows: int, D: int, eps: float, stat: torch.Tensor):
+def ln_finish(part: torch.Tensor, rows: int, D: int, eps: float, stat: torch.Tensor, watch: Optional[torch.Tensor] = None, watch_limit: float = 0.0):
     """stat[rows,2] = mean, rstd of the rows whose sums a stream product left in ``part`` [rows, D/64, 2]."""
     _dev(part, stat)
     _req(part.dtype == torch.float32 and stat.dtype == torch.float32 and part.is_contiguous() and stat.is_contiguous(), "ln_finish: f32 contiguous")
     _req(D % 64 == 0 and part.numel() >= rows * (D // 64) * 2 and stat.numel() >= 2 * rows, "ln_finish: sizes")
-    hip.check(hip.lib().marship_ln_finish(ptr(part), D // 64, rows, D, eps, ptr(stat), stream()), "marship_ln_finish")
+    _req(watch is None or (watch.dtype == torch.float32 and watch.numel() >= 1), "ln_finish: watch must be f32")
+    if watch is not None:
+        _dev(watch)
+    hip.check(hip.lib().marship_ln_finish(ptr(part), D // 64, rows, D, eps, ptr(stat), ptr(watch), watch_limit, stream()), "marship_ln_finish")
 
 
-def row_stats(x: torch.Tensor, eps: float, hi: torch.Tensor, lo: torch.Tensor, stat: torch.Tensor):
+def row_stats(x: torch.Tensor, eps: float, hi: torch.Tensor, lo: torch.Tensor, stat: torch.Tensor, watch: Optional[torch.Tensor] = None,
+              watch_limit: float = 0.0):
     """hi = bf16(x), lo = bf16(x - hi), stat[rows,2] = mean, rstd of the f32 rows of x."""
     _dev(x, hi, lo, stat)
     _req(x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "row_stats: x must be f32 rows")
@@ -228,8 +232,11 @@ def row_stats(x: torch.Tensor, eps: float, hi: torch.Tensor, lo: torch.Tensor, s
     _req(hi.stride(0) == lo.stride(0), "row_stats: planes must share a row stride")
     _req(stat.dtype == torch.float32 and stat.is_contiguous() and stat.numel() >= 2 * rows, "row_stats: stat")
     _req((rows - 1) * x.stride(0) + D <= _avail(x), "row_stats: overrun")
-    hip.check(hip.lib().marship_row_stats(ptr(x), x.stride(0), rows, D, eps, ptr(hi), ptr(lo), hi.stride(0), ptr(stat), stream()),
-              "marship_row_stats")
+    _req(watch is None or (watch.dtype == torch.float32 and watch.numel() >= 1), "row_stats: watch must be f32")
+    if watch is not None:
+        _dev(watch)
+    hip.check(hip.lib().marship_row_stats(ptr(x), x.stride(0), rows, D, eps, ptr(hi), ptr(lo), hi.stride(0), ptr(stat), ptr(watch), watch_limit,
+                                          stream()), "marship_row_stats")
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float):
@@ -253,6 +260,18 @@ def im2col(img: torch.Tensor, p: int, out: torch.Tensor, *, mean=None, std=None,
         _req(mean.numel() == C and std.numel() == C and mean.dtype == torch.float32, "im2col: mean/std size")
     hip.check(hip.lib().marship_im2col(ptr(img), 1 if img.dtype == torch.uint8 else 0, B, C, H, W, p, ptr(mean), ptr(std),
                                        prescale, ptr(out), out.stride(0), col_off, dt(out), stream()), "marship_im2col")
+
+
+def embed_tokens(table: torch.Tensor, ids: torch.Tensor, pos: torch.Tensor, X: torch.Tensor):
+    """X[n, l] = table[ids[n, l]] + pos[l]; table f32 [vocab, D], ids int32 [n, L], pos f32 [L, D], X f32 [n, L, D]."""
+    _dev(table, ids, pos, X)
+    _req(table.dim() == 2 and table.is_contiguous() and table.dtype == torch.float32, "embed_tokens: table must be contiguous f32 [vocab, D]")
+    _req(ids.dim() == 2 and ids.is_contiguous() and ids.dtype == torch.int32, "embed_tokens: ids must be contiguous int32 [n, L]")
+    n, L = ids.shape
+    D = table.shape[1]
+    _req(pos.dtype == torch.float32 and pos.is_contiguous() and tuple(pos.shape) == (L, D), "embed_tokens: pos must be contiguous f32 [L, D]")
+    _req(X.dtype == torch.float32 and X.is_contiguous() and tuple(X.shape) == (n, L, D), "embed_tokens: X must be contiguous f32 [n, L, D]")
+    hip.check(hip.lib().marship_embed_tokens(ptr(table), table.shape[0], ptr(ids), ptr(pos), ptr(X), n * L, L, D, stream()), "marship_embed_tokens")
 
 
 def write_prefix_tokens(X: torch.Tensor, cls: torch.Tensor, pos0: Optional[torch.Tensor], regs: Optional[torch.Tensor]):

@@ -307,6 +307,64 @@ def test_gemm_folded_layernorm(pkg, cuda, M, D, N2, K2):
         assert e_fold < 1.5 * e_alone + 1e-3, (e_fold, e_alone)
 
 
+@pytest.mark.parametrize("ratio", [0.4, 10.0, 30.0])
+def test_gemm_folded_layernorm_rows_with_large_means(pkg, cuda, ratio):
+    """The folded form rounds x to bf16, the stand-alone pass x - mean: on rows with a common offset of `ratio`
+    standard deviations (and a few outlier channels on top) the folded product is further from the f64 result by
+    about that factor, never by more than 1.5 * (1 + ratio) times the stand-alone error; the statistics kernels
+    report the rows beyond a limit."""
+    ops = pkg.ops
+    M, D, N2, eps = 1024, 1024, 512, 1e-5
+    x = _rand((M, D), 11, cuda)
+    x[:, 5] *= 20.0                                                # outlier channels, as residual streams have
+    x[:, 700] *= -12.0
+    x = x / x.std(1, keepdim=True)
+    x = x + ratio * torch.sign(_rand((M, 1), 12, cuda))            # rows at +-ratio standard deviations
+    hi, lo = torch.zeros(M, D, device=cuda, dtype=torch.bfloat16), torch.zeros(M, D, device=cuda, dtype=torch.bfloat16)
+    stat, watch = torch.zeros(M, 2, device=cuda), torch.zeros(1, device=cuda)
+    ops.row_stats(x, eps, hi, lo, stat, watch, 8.0)
+    got = float(watch[0])
+    true_ratio = float((x.double().mean(1).abs() / x.double().std(1, unbiased=False)).max())
+    if ratio < 8.0:
+        assert got == 0.0
+    else:
+        assert abs(got - true_ratio) < 1e-3 * true_ratio
+    # the same report from the sums a producing epilogue leaves
+    part = torch.stack([x.view(M, D // 64, 64).sum(2), (x * x).view(M, D // 64, 64).sum(2)], dim=2).contiguous()
+    stat2, watch2 = torch.zeros(M, 2, device=cuda), torch.zeros(1, device=cuda)
+    ops.ln_finish(part, M, D, eps, stat2, watch2, 8.0)
+    assert float((stat2 - stat).abs().max()) < 1e-3
+    assert (float(watch2[0]) == 0.0) if ratio < 8.0 else abs(float(watch2[0]) - true_ratio) < 1e-2 * true_ratio
+    lnw, lnb = _rand((D,), 6, cuda) * 0.2 + 1.0, _rand((D,), 7, cuda) * 0.1
+    w1, b1 = _rand((N2, D), 8, cuda) * 0.05, _rand((N2,), 9, cuda) * 0.1
+    wf, bf = pkg.models._fold_norm(w1, b1, lnw, lnb)
+    wf = wf.to(torch.bfloat16)
+    colsum = wf.float().sum(1).contiguous()
+    out = torch.zeros(M, N2, device=cuda, dtype=torch.bfloat16)
+    ops.linear(hi, wf, out, bias=bf, ln_in=(stat, colsum))
+    ln = torch.nn.functional.layer_norm(x, (D,), lnw, lnb, eps)
+    z = ln.double() @ w1.double().t() + b1.double()[None]
+    alone = torch.zeros(M, N2, device=cuda, dtype=torch.bfloat16)
+    ops.linear(ln.to(torch.bfloat16), w1.to(torch.bfloat16), alone, bias=b1)
+    e_fold = float((out.double() - z).abs().mean())
+    e_alone = float((alone.double() - z).abs().mean())
+    assert e_fold < 1.5 * (1.0 + ratio) * e_alone, (ratio, e_fold, e_alone)
+    if ratio >= 10.0:
+        assert e_fold > 2.0 * e_alone, (ratio, e_fold, e_alone)   # the loss is real: hence the report
+
+
+def test_embed_tokens_matches_torch(pkg, cuda):
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(3)
+    table, pos = torch.randn(300, 96, generator=g).to(cuda), torch.randn(11, 96, generator=g).to(cuda)
+    ids = torch.randint(0, 300, (5, 11), generator=g).int().to(cuda)
+    X = torch.full((5, 11, 96), float("nan"), device=cuda)
+    ops.embed_tokens(table, ids, pos, X)
+    assert torch.equal(X, table[ids.long()] + pos[None])
+    with pytest.raises(Exception):
+        ops.embed_tokens(table, ids.long(), pos, X)
+
+
 def test_gemm_folded_layernorm_is_refused_where_no_kernel_takes_it(pkg, cuda):
     ops = pkg.ops
     M, D = 128, 128

@@ -173,6 +173,47 @@ def test_alphaclip_folded_layernorms(pkg, cuda):
     assert maxdiff(folded.visual(img1, alpha), ff) < 0.05 * max(1.0, float(ff.abs().max()))
 
 
+def test_alphaclip_folded_layernorms_fall_back_on_large_row_means(pkg, cuda):
+    """A residual stream whose rows sit far from zero (|mean| / std of about 30: a shifted ln_pre bias) is what the
+    folded form is bad at; the folded runs report it, and from the next call on the tower runs its LayerNorms
+    stand-alone: same features as a tower built that way.  A stream with ordinary rows keeps the folded form."""
+    synth = pkg.synth
+    cfg = synth.CLIP_ARCHS["tiny/14"]
+    sd = synth.clip_state_dict(cfg, seed=4, alpha=True)
+    R = cfg.image_resolution
+    img1 = synth.randn(7, "aclip_img", (1, 3, R, R), 1.0).to(cuda)
+    alpha = synth.randn(7, "aclip_alpha", (3, 1, R, R), 1.5).to(cuda)
+    M = _models(pkg)
+    calm = M.AlphaCLIP(cfg, sd, device=cuda, dtype=torch.bfloat16, fold_ln=True)
+    for _ in range(3):
+        calm.visual(img1, alpha)
+        torch.cuda.synchronize()
+    assert calm.fold_ln and calm.vtower.blocks[0].folded
+    shifted = dict(sd)
+    shifted["visual.ln_pre.bias"] = sd["visual.ln_pre.bias"] + 30.0
+    folded = M.AlphaCLIP(cfg, shifted, device=cuda, dtype=torch.bfloat16, fold_ln=True)
+    alone = M.AlphaCLIP(cfg, shifted, device=cuda, dtype=torch.bfloat16, fold_ln=False)
+    want = alone.visual(img1, alpha).clone()
+    first = folded.visual(img1, alpha).clone()                  # still folded: nothing has been reported yet
+    torch.cuda.synchronize()
+    assert folded.fold_ln
+    with pytest.warns(UserWarning, match="stand-alone"):
+        second = folded.visual(img1, alpha).clone()
+    assert not folded.fold_ln and not folded.vtower.blocks[0].folded
+    assert torch.equal(second, want)
+    # what the report is about: the folded features of such a stream are further from the stand-alone ones than
+    # the two forms are from each other on an ordinary stream
+    ordinary = maxdiff(calm.visual(img1, alpha), M.AlphaCLIP(cfg, sd, device=cuda, dtype=torch.bfloat16, fold_ln=False).visual(img1, alpha))
+    assert maxdiff(first, want) > ordinary
+    # MARS_FOLD_LN_LIMIT <= 0 (here: the attribute it sets): nobody looks
+    blind = M.AlphaCLIP(cfg, shifted, device=cuda, dtype=torch.bfloat16, fold_ln=True)
+    blind.fold_limit = 0.0
+    for _ in range(2):
+        blind.visual(img1, alpha)
+        torch.cuda.synchronize()
+    assert blind.fold_ln
+
+
 def test_backbone_loader_seam(pkg, cuda):
     BL = importlib.import_module(pkg.__name__ + ".utils.backbone_loader").BackboneLoader
     enc, tr = BL.load_backbone("dinov2", "vit_tiny2", None, "cuda:0", dict(img_size=70, patch_size=14, num_register_tokens=4, seed=1))

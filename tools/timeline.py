@@ -55,9 +55,10 @@ def wrap(obj, name, before=None, after=None, ev_after=True):
 
 
 fmm = mars.filtering_merging_component
-wrap(mars.visual_visual_alignment_component, "compute", before="start", after="vva queued")
+wrap(mars, "_predict", before="start")
+wrap(mars.visual_visual_alignment_component, "compute", before="vva begins", after="vva queued")
 wrap(mars.visual_text_alignment_component, "compute", after="vta queued")
-wrap(fmm, "_compute_alphaclip_vis_feats", after="alphaclip queued")
+wrap(fmm, "_compute_alphaclip_vis_feats", before="alphaclip begins", after="alphaclip queued")
 orig_emd = fmm._compute_emd_scores
 
 
