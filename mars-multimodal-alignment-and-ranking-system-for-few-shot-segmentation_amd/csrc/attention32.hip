@@ -568,22 +568,33 @@ __global__ __launch_bounds__(256, 2) void flash_attn_w32_kernel(const __bf16* __
         MARS_T(t_done)
         const int myq = q0 + r32;
         const float ltot = halves_sum(lsum);
-        if (wave_active && myq < T) {
+        if (wave_active) {
             int bh, qb_;
             attn_block(id, nbh, nqb, xcd_aware, bh, qb_);
-            const float inv = 1.0f / ltot;
+            const float inv = __builtin_amdgcn_rcpf(ltot);      // (1 ulp: the outputs are rounded to bf16)
             __bf16* op = O + ((int64_t)(bh / H) * T + myq) * D + (bh % H) * 64;
+            // A lane holds four consecutive dims of each group of eight, its partner in the other half-wave (same
+            // query) the other four.  Two groups at a time, the half-waves trade halves (v_permlane32_swap on the
+            // packed pairs: the lower lane ends up with all eight dims of the first group, the upper lane with those
+            // of the second) and every lane stores 16 bytes.
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    bf16x4 v;
+                for (int rp = 0; rp < 2; ++rp) {
+                    bf16x4 a, b;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (__bf16)(o[db][4 * rg + j] * inv);
-                    *(bf16x4*)(op + 32 * db + 8 * rg + 4 * hh) = v;
+                    for (int j = 0; j < 4; ++j) {
+                        a[j] = (__bf16)(o[db][8 * rp + j] * inv);
+                        b[j] = (__bf16)(o[db][8 * rp + 4 + j] * inv);
+                    }
+                    const v2i32 ai = __builtin_bit_cast(v2i32, a), bi = __builtin_bit_cast(v2i32, b);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)ai[0], (unsigned)bi[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)ai[1], (unsigned)bi[1], false, false);
+                    const v4i32 out = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                    if (myq < T) *(v4i32*)(op + 32 * db + 8 * (2 * rp + hh)) = out;
                 }
             // natural-log LSE of the scaled scores: (max + log2(sum)) * ln 2
-            if (lse && hh == 0) lse[(int64_t)bh * T + myq] = (mrun + log2f(ltot)) * 0.69314718055994530942f;
+            if (lse && hh == 0 && myq < T) lse[(int64_t)bh * T + myq] = (mrun + __builtin_amdgcn_logf(ltot)) * 0.69314718055994530942f;
         }
         MARS_T(t_fin)
         MARS_ACC(st_fin, t_done, t_fin)
