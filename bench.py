@@ -348,10 +348,17 @@ def main():
 
     host = {"emd_ms": [], "emd_end_ms": [], "step_ms": []}       # per timed step of this rank
 
+    # warm-up steps go through everything a timed step does, the meter included (into one of their own): the runtime
+    # loads a code object when one of its kernels is first launched, and the first `index_add_` of a process brings
+    # in torch's indexing module (about 120 ms) - inside the timed region if the warm-up had skipped the meter
+    warm_meter = AverageMeter(dataset, device=dev)
+
     def step(ep, count=True):
         t_s = time.perf_counter()
         pred = mars.predict(ep["support_imgs"], ep["support_masks"], ep["query_img"], ep["mask_proposals"])
         ai, au = Evaluator.classify_prediction(pred[None], ep)
+        if not count:
+            warm_meter.update(ai, au, ep["class_id"])
         if count:
             meter.update(ai, au, ep["class_id"])
             tm = getattr(mars.filtering_merging_component, "timing", {})
