@@ -590,6 +590,78 @@ def test_fp8_attention_close_to_reference(pkg, cuda, B, T, H):
     assert float((O2.float() - ref2).abs().max()) < 0.15 * float(ref2.abs().max())
 
 
+def _attention_reference(qkv, B, T, H):
+    q = qkv.float().view(B, T, 3, H, 64)
+    s = torch.einsum("bthd,bshd->bhts", q[:, :, 0], q[:, :, 1]) * 0.6931471805599453          # stored queries carry log2(e)/8
+    return torch.einsum("bhts,bshd->bthd", s.softmax(-1), q[:, :, 2]).reshape(B * T, H * 64), torch.logsumexp(s, -1).reshape(B * H, T)
+
+
+@pytest.mark.parametrize("B,T,H", [(8, 577, 16), (16, 577, 16), (12, 600, 12), (9, 321, 13)])
+def test_flash_attention_walking_workgroups(pkg, cuda, B, T, H):
+    """Launches with more (image-head, query block) items than the chip holds workgroups: every workgroup walks
+    several items, the next one's queries and first tiles brought in under the current one, and - from twice as many
+    items as workgroups - takes its third and later items from the launch's counters.  Against the f32 softmax; a
+    second launch on the same stream (it finds the counters as the first left them) gives the same bits, and so do two
+    launches side by side on streams of their own."""
+    ops = pkg.ops
+    D = H * 64
+    x = _rand((B * T, 3 * D), 41, cuda) * 1.2
+    x[:, :D] *= ops.RAW_QUERY_SCALE_LOG2
+    qkv = x.to(torch.bfloat16)
+    ref, want_lse = _attention_reference(qkv, B, T, H)
+
+    def run(stream=None):
+        O = torch.full((B * T, D), float("nan"), device=cuda, dtype=torch.bfloat16)
+        lse = torch.zeros(B * H, T, device=cuda)
+        if stream is None:
+            ops.flash_attn(qkv, O, lse, B, T, H, False, score_scale_log2=1.0)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                ops.flash_attn(qkv, O, lse, B, T, H, False, score_scale_log2=1.0)
+        return O, lse
+
+    O1, l1 = run()
+    assert bool(torch.isfinite(O1.float()).all())
+    assert float((O1.float() - ref).abs().max()) < 3e-2
+    assert float((l1 - want_lse).abs().max()) < 4e-3
+    O2, l2 = run()
+    assert torch.equal(O1, O2) and torch.equal(l1, l2)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    (Oa, la), (Ob, lb) = run(sa), run(sb)
+    torch.cuda.current_stream().wait_stream(sa)
+    torch.cuda.current_stream().wait_stream(sb)
+    torch.cuda.synchronize()
+    assert torch.equal(Oa, O1) and torch.equal(Ob, O1) and torch.equal(la, l1) and torch.equal(lb, l1)
+    O3, _ = run()                                  # and the default stream's counters are still in order
+    assert torch.equal(O3, O1)
+
+
+def test_flash_attention_walking_workgroups_second_pass(pkg, cuda):
+    """A few items of a walking launch leave the absolute scale's range (one key lined up with one query at +150 nats,
+    another at key 0): their workgroups work them again with the running maximum - the rings set up afresh in the
+    middle of a walk, the next item's queries staged twice - and go on to their next items."""
+    ops = pkg.ops
+    B, T, H = 10, 577, 16
+    D = H * 64
+    x = _rand((B * T, 3 * D), 43, cuda) * 0.8
+    for b, t, key, head, nats in [(0, 5, 300, 0, 150.0), (3, 200, 0, 7, 120.0), (9, 576, 575, 15, 150.0), (4, 130, 64, 2, -150.0)]:
+        q = x[b * T + t, head * 64:head * 64 + 64]
+        x[b * T + key, D + head * 64:D + head * 64 + 64] = q / q.norm() ** 2 * (8.0 * nats)       # q . k / 8 = nats
+    x[:, :D] *= ops.RAW_QUERY_SCALE_LOG2
+    qkv = x.to(torch.bfloat16)
+    ref, want_lse = _attention_reference(qkv, B, T, H)
+    O = torch.full((B * T, D), float("nan"), device=cuda, dtype=torch.bfloat16)
+    lse = torch.zeros(B * H, T, device=cuda)
+    ops.flash_attn(qkv, O, lse, B, T, H, False, score_scale_log2=1.0)
+    assert bool(torch.isfinite(O.float()).all())
+    assert float((O.float() - ref).abs().max()) < 3e-2
+    assert float(((lse - want_lse).abs() / want_lse.abs().clamp_min(1.0)).max()) < 1.2e-2
+    O2 = torch.empty_like(O)
+    ops.flash_attn(qkv, O2, lse, B, T, H, False, score_scale_log2=1.0)
+    assert torch.equal(O, O2)
+
+
 def test_flash_attention_spiked_scores(pkg, cuda):
     """A key that dominates a row late in the sequence forces the online-softmax rescale."""
     T, H = 200, 1
