@@ -1,5 +1,5 @@
 // Diagnostic build of the 32x32x16 fused attention kernel with per-wave phase clocks.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-honor-nans -mno-amdgpu-ieee tools/diag_attn32.hip -o tools/diag_bin/diag_attn32
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-honor-nans -mno-amdgpu-ieee -fno-slp-vectorize tools/diag_attn32.hip -o tools/diag_bin/diag_attn32
 //   diag_attn32 B T H
 #define MARS_STAMPS 1
 #include "../mars-multimodal-alignment-and-ranking-system-for-few-shot-segmentation_amd/csrc/attention32.hip"
