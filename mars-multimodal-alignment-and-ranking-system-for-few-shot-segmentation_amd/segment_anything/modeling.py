@@ -343,6 +343,13 @@ class _DecAttn:
         mk = lambda n: Lin(*_pad_heads_rows(sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"], heads, self.hd, self.hdp), dtype, device)
         self.q, self.k, self.v = mk("q_proj"), mk("k_proj"), mk("v_proj")
         self.o = Lin(_pad_heads_cols(sd[p + ".out_proj.weight"], heads, self.hd, self.hdp), sd[p + ".out_proj.bias"], dtype, device)
+        # Heads of 16 or 32 dims with a handful of tokens on one side (every product of the two-way transformer) run
+        # on unpadded projections and ops.attn_small: the padded form above moves four times the bytes at 16 dims a head.
+        # MARS_SAM_SMALL_ATTN=0 keeps the padded form.
+        self.small = self.hd in (16, 32) and heads in (1, 2, 4, 8, 16, 32, 64) and os.environ.get("MARS_SAM_SMALL_ATTN", "1") != "0"
+        if self.small:
+            mks = lambda n: Lin(sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"], dtype, device)
+            self.qs, self.ks, self.vs, self.os = mks("q_proj"), mks("k_proj"), mks("v_proj"), mks("out_proj")
 
 
 class MaskDecoder:
@@ -392,6 +399,16 @@ class MaskDecoder:
 
     def _attention(self, A: _DecAttn, tag: str, q_in, k_in, v_in, nb: int, Tq: int, Tk: int, out: torch.Tensor, residual):
         """transformer.py:218-240: q_in [nb*Tq, C], k_in / v_in [nb*Tk, C] in the compute dtype -> out f32 (+ residual)."""
+        if A.small and (Tk <= 16 or Tq <= 16):
+            W = A.H * A.hd
+            q = self._buf(tag + "qs", (nb * Tq, W)); k = self._buf(tag + "ks", (nb * Tk, W)); v = self._buf(tag + "vs", (nb * Tk, W))
+            ops.linear(q_in, A.qs.w, q, bias=A.qs.b)
+            ops.linear(k_in, A.ks.w, k, bias=A.ks.b)
+            ops.linear(v_in, A.vs.w, v, bias=A.vs.b)
+            o = self._buf(tag + "os", (nb * Tq, _pad_to(W, 64)))         # (K of the output projection, padded like its weight)
+            ops.attn_small(q, k, v, o, nb, A.H, A.hd, Tq, Tk, 1.0 / math.sqrt(A.hd))
+            ops.linear(o, A.os.w, out, bias=A.os.b, residual=residual)
+            return
         W = A.H * A.hdp
         q = self._buf(tag + "q", (nb * Tq, W)); k = self._buf(tag + "k", (nb * Tk, W)); v = self._buf(tag + "v", (nb * Tk, W))
         ops.linear(q_in, A.q.w, q, bias=A.q.b)
