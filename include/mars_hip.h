@@ -309,6 +309,20 @@ int marship_add_cast(const float* a, const float* b, int64_t b_rows, void* out, 
                      int out_dtype, void* stream);
 /* Elementwise activation with a type change (act 0 none, 1 GELU(erf), 3 ReLU): mask_decoder.py:56. */
 int marship_act_cast(const float* in, void* out, int64_t n, int act, int out_dtype, void* stream);
+/* One pass over the rows of the decoder's image-side stream (transformer.py:151-183: norm4 of a layer, then the
+ * `keys + key_pe` and `keys` operands of the next attention): y = LayerNorm(x) (w, b non-null; stored as f32 in `y` if
+ * that is non-null, which may be x itself) or y = x; c0 = y + add[r % add_rows] and c1 = y in out_dtype (either may be
+ * null).  x f32 [rows, D] contiguous, D a multiple of 4 up to 2048. */
+int marship_stream_copies(const float* x, const float* w, const float* b, float eps, float* y, const float* add,
+                          int64_t add_rows, void* c0, void* c1, int64_t rows, int D, int out_dtype, void* stream);
+/* LayerNorm over rows of D <= 256 channels, then an activation (0 none, 1 erf GELU), f32 -> out_dtype with row stride
+ * ldo: LayerNorm2d + GELU of the output upscaling (mask_decoder.py:53-59, common.py:31-43). */
+int marship_layernorm_act_rows(const float* x, const float* w, const float* b, float eps, void* out, int64_t ldo,
+                               int64_t rows, int D, int act, int out_dtype, void* stream);
+/* masks[b, m, p] = sum_c hyper[b, m, c] * up[b*P + p, c], four masks a prompt, C <= 64 channels (mask_decoder.py:141-143:
+ * hyper_in @ upscaled_embedding); hyper f32 [B*4, ldh], up f32 [B*P, ldu], masks f32 [B, 4, P]. */
+int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int64_t ldu, float* masks, int B,
+                          int64_t P, int C, void* stream);
 /* Per mask of logits [n, H, W] (utils/amg.py:155-175, 310-353): out[k] = {#(> thr+off), #(> thr-off),
  * x0, y0, x1, y1 of (> thr)} (int32 x 6; the box of an empty mask is 0,0,0,0). */
 int marship_mask_stats(const float* masks, int n, int H, int W, float thr, float off, int32_t* out,

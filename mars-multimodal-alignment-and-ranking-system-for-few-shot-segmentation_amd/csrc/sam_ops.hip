@@ -232,6 +232,136 @@ __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__
     }
 }
 
+// One pass over the rows of the image-side stream of the mask decoder (D = 64 * NCH * 4 at most, a wave per row):
+//   y = LayerNorm(x) (w, b given; written back as f32 when `y` is set) or y = x,
+//   c0 = y + add[r % add_rows]  and  c1 = y  in the compute type (either may be null),
+// i.e. the LayerNorm that ends a layer together with the two casts the next layer's projections read.
+template <typename TOUT, int NCH>
+__global__ __launch_bounds__(256) void stream_copies_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                            float eps, float* __restrict__ y, const float* __restrict__ add, int64_t add_rows,
+                                                            TOUT* __restrict__ c0, TOUT* __restrict__ c1, int64_t rows, int D) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, nc = D >> 2;
+    const f32x4* xr = (const f32x4*)(x + row * D);
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    if (w) {
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nc) {
+                v[i] -= mean;
+                q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nc) v[i] = v[i] * rstd * ((const f32x4*)w)[c] + ((const f32x4*)b)[c];
+        }
+    }
+    const f32x4* ar = add ? (const f32x4*)(add + (row % add_rows) * D) : nullptr;
+    auto put = [&](TOUT* dst, const f32x4& o, int c) {
+        if constexpr (sizeof(TOUT) == 4) ((f32x4*)dst)[c] = o;
+        else { bf16x4 ob; ob[0] = (__bf16)o[0]; ob[1] = (__bf16)o[1]; ob[2] = (__bf16)o[2]; ob[3] = (__bf16)o[3]; ((bf16x4*)dst)[c] = ob; }
+    };
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) {
+            if (y) ((f32x4*)(y + row * D))[c] = v[i];
+            if (c1) put(c1 + row * D, v[i], c);
+            if (c0) put(c0 + row * D, ar ? v[i] + ar[c] : v[i], c);
+        }
+    }
+}
+
+// LayerNorm over rows of D (a multiple of 4, at most 256) followed by an activation (0 none, 1 erf GELU), f32 in,
+// compute type out: LayerNorm2d + GELU between the two transposed convolutions (mask_decoder.py:53-59).  Sixteen
+// lanes a row (D = 64: one float4 a lane), so a wave covers four rows.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void layernorm_act_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                                 float eps, TOUT* __restrict__ out, int64_t ldo, int64_t rows, int D, int act) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int l16 = threadIdx.x & 15, nc = D >> 2;
+    const bool live = row < rows;
+    const f32x4* xr = (const f32x4*)(x + (live ? row : 0) * D);
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 16 + l16;
+        if (c < nc) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 16 + l16;
+        if (c < nc) {
+            v[i] -= mean;
+            q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 16 + l16;
+        if (c < nc) {
+            f32x4 o = v[i] * rstd * ((const f32x4*)w)[c] + ((const f32x4*)b)[c];
+            if (act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = 0.5f * o[e] * (1.0f + erff(o[e] * 0.70710678118654752440f));
+            }
+            TOUT* dst = out + row * ldo;
+            if constexpr (sizeof(TOUT) == 4) ((f32x4*)dst)[c] = o;
+            else { bf16x4 ob; ob[0] = (__bf16)o[0]; ob[1] = (__bf16)o[1]; ob[2] = (__bf16)o[2]; ob[3] = (__bf16)o[3]; ((bf16x4*)dst)[c] = ob; }
+        }
+    }
+}
+
+// masks[b, m, p] = sum_c hyper[b, m, c] * up[b*P + p, c]  for NM = 4 masks and C <= 64 channels (a multiple of 4): the
+// product of the hypernetwork outputs with the upscaled embedding (mask_decoder.py:141-143).  A thread owns one
+// pixel: it reads its row of `up` once (16-byte loads) and the prompt's four vectors from LDS; a workgroup's pixels are
+// consecutive, so the four result rows are written coalesced.
+__global__ __launch_bounds__(256) void hyper_product_kernel(const float* __restrict__ hyper, int64_t ldh, const float* __restrict__ up, int64_t ldu,
+                                                            float* __restrict__ masks, int64_t P, int C) {
+    __shared__ float hs[4 * 64];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 4 * C) hs[(threadIdx.x / C) * 64 + threadIdx.x % C] = hyper[((int64_t)b * 4 + threadIdx.x / C) * ldh + threadIdx.x % C];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const f32x4* ur = (const f32x4*)(up + ((int64_t)b * P + p) * ldu);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = 0; c < C; c += 4) {
+        const f32x4 u = ur[c >> 2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a0 = fmaf(hs[c + e], u[e], a0);
+            a1 = fmaf(hs[64 + c + e], u[e], a1);
+            a2 = fmaf(hs[128 + c + e], u[e], a2);
+            a3 = fmaf(hs[192 + c + e], u[e], a3);
+        }
+    }
+    float* mo = masks + (int64_t)b * 4 * P + p;
+    mo[0] = a0; mo[P] = a1; mo[2 * P] = a2; mo[3 * P] = a3;
+}
+
 // elementwise activation (1 = erf GELU, 3 = ReLU) with a type change
 template <typename TOUT>
 __global__ __launch_bounds__(256) void act_cast_kernel(const float* __restrict__ in, TOUT* __restrict__ out, int64_t n, int act) {
@@ -361,6 +491,48 @@ extern "C" int marship_add_cast(const float* a, const float* b, int64_t b_rows, 
     MARS_CHECK(a && out && rows > 0 && D > 0 && (!b || b_rows > 0), "add_cast: bad arguments");
     if (out_dtype == 1) hipLaunchKernelGGL(add_cast_kernel<__bf16>, dim3(blocks_for(rows * D)), dim3(256), 0, (hipStream_t)stream, a, b, b_rows, (__bf16*)out, rows, D);
     else hipLaunchKernelGGL(add_cast_kernel<float>, dim3(blocks_for(rows * D)), dim3(256), 0, (hipStream_t)stream, a, b, b_rows, (float*)out, rows, D);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_stream_copies(const float* x, const float* w, const float* b, float eps, float* y, const float* add, int64_t add_rows,
+                                     void* c0, void* c1, int64_t rows, int D, int out_dtype, void* stream) {
+    MARS_CHECK(x && rows > 0 && D > 0 && D % 4 == 0 && D <= 2048, "stream_copies: bad shape rows=%lld D=%d", (long long)rows, D);
+    MARS_CHECK((w == nullptr) == (b == nullptr) && (!y || w), "stream_copies: LayerNorm needs weight and bias; y is its f32 result");
+    MARS_CHECK(!add || add_rows > 0, "stream_copies: add_rows");
+    MARS_CHECK((((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y | (uintptr_t)add) % 16) == 0 && (((uintptr_t)c0 | (uintptr_t)c1) % 8) == 0,
+               "stream_copies: alignment");
+    MARS_CHECK(out_dtype == 0 || out_dtype == 1, "stream_copies: out_dtype %d", out_dtype);
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nch = (D / 4 + 63) / 64;
+#define MARS_SC(N)                                                                                                                     \
+    if (out_dtype == 1) hipLaunchKernelGGL((stream_copies_kernel<__bf16, N>), grid, block, 0, (hipStream_t)stream, x, w, b, eps, y, add, add_rows, \
+                                           (__bf16*)c0, (__bf16*)c1, rows, D);                                                          \
+    else hipLaunchKernelGGL((stream_copies_kernel<float, N>), grid, block, 0, (hipStream_t)stream, x, w, b, eps, y, add, add_rows, (float*)c0, (float*)c1, rows, D);
+    if (nch <= 1) { MARS_SC(1) } else if (nch <= 2) { MARS_SC(2) } else if (nch <= 4) { MARS_SC(4) } else { MARS_SC(8) }
+#undef MARS_SC
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_layernorm_act_rows(const float* x, const float* w, const float* b, float eps, void* out, int64_t ldo, int64_t rows, int D,
+                                          int act, int out_dtype, void* stream) {
+    MARS_CHECK(x && w && b && out && rows > 0, "layernorm_act_rows: bad arguments");
+    MARS_CHECK(D > 0 && D % 4 == 0 && D <= 256 && ldo >= D && (act == 0 || act == 1), "layernorm_act_rows: D=%d act=%d", D, act);
+    MARS_CHECK((((uintptr_t)x | (uintptr_t)w | (uintptr_t)b) % 16) == 0 && ((uintptr_t)out % 16) == 0 && (ldo * (out_dtype == 1 ? 2 : 4)) % 8 == 0,
+               "layernorm_act_rows: alignment");
+    const dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    if (out_dtype == 1) hipLaunchKernelGGL(layernorm_act_rows_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, w, b, eps, (__bf16*)out, ldo, rows, D, act);
+    else hipLaunchKernelGGL(layernorm_act_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, x, w, b, eps, (float*)out, ldo, rows, D, act);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int64_t ldu, float* masks, int B, int64_t P, int C,
+                                     void* stream) {
+    MARS_CHECK(hyper && up && masks && B > 0 && B <= 65535 && P > 0, "hyper_product: bad arguments");
+    MARS_CHECK(C > 0 && C <= 64 && C % 4 == 0 && ldh >= C && ldu >= C && ldu % 4 == 0 && ((uintptr_t)up % 16) == 0, "hyper_product: C=%d / row layout", C);
+    hipLaunchKernelGGL(hyper_product_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, hyper, ldh, up, ldu, masks, P, C);
     MARS_LAUNCH_CHECK();
     return 0;
 }

@@ -691,6 +691,48 @@ def add_cast(a: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor):
     hip.check(hip.lib().marship_add_cast(ptr(a), ptr(b), b_rows, ptr(out), rows, D, dt(out), stream()), "marship_add_cast")
 
 
+def stream_copies(x: torch.Tensor, c0: Optional[torch.Tensor], c1: Optional[torch.Tensor], *, add: Optional[torch.Tensor] = None, norm=None,
+                  eps: float = 1e-5, write_back: bool = True):
+    """One pass over x f32 [rows, D]: y = LayerNorm(x) with ``norm`` = (weight, bias) (written back into x when
+    ``write_back``) or y = x; c0 = y + add (add broadcast over leading rows by repetition), c1 = y, both in their dtype."""
+    _dev(x, c0, c1, add)
+    _req(x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2, "stream_copies: x must be contiguous f32 [rows, D]")
+    rows, D = x.shape
+    outs = [t for t in (c0, c1) if t is not None]
+    _req(len(outs) > 0 or (norm is not None and write_back), "stream_copies: nothing to write")
+    for t in outs:
+        _req(t.is_contiguous() and t.numel() == x.numel() and t.dtype == outs[0].dtype and t.dtype in (torch.float32, torch.bfloat16), "stream_copies: copies")
+    add_rows = 1
+    if add is not None:
+        _req(add.dtype == torch.float32 and add.is_contiguous() and add.shape[-1] == D and rows % (add.numel() // D) == 0, "stream_copies: add")
+        add_rows = add.numel() // D
+    w = b = None
+    if norm is not None:
+        w, b = norm
+        _dev(w, b)
+        _req(w.numel() == D and b.numel() == D and w.dtype == torch.float32 and b.dtype == torch.float32, "stream_copies: norm")
+    hip.check(hip.lib().marship_stream_copies(ptr(x), ptr(w), ptr(b), eps, ptr(x) if (norm is not None and write_back) else None, ptr(add), add_rows,
+                                              ptr(c0), ptr(c1), rows, D, dt(outs[0]) if outs else 0, stream()), "marship_stream_copies")
+
+
+def layernorm_act_rows(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float, act: int):
+    """out[:, :D] = act(LayerNorm(x)) for x f32 [rows, D <= 256]; out [rows, >= D] in its dtype (row stride = stride(0))."""
+    _dev(x, w, b, out)
+    _req(x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= x.shape[0]
+         and out.shape[1] >= x.shape[1], "layernorm_act_rows: layout")
+    hip.check(hip.lib().marship_layernorm_act_rows(ptr(x), ptr(w), ptr(b), eps, ptr(out), out.stride(0), x.shape[0], x.shape[1], act, dt(out), stream()),
+              "marship_layernorm_act_rows")
+
+
+def hyper_product(hyper: torch.Tensor, up: torch.Tensor, masks: torch.Tensor, B: int, P: int, C: int):
+    """masks[b, m, p] = hyper[b, m, :C] . up[b*P + p, :C]; hyper f32 [B, 4, >= C], up f32 [B*P, >= C], masks f32 [B, 4, P]."""
+    _dev(hyper, up, masks)
+    _req(hyper.dtype == torch.float32 and up.dtype == torch.float32 and masks.dtype == torch.float32, "hyper_product: f32 operands")
+    _req(hyper.dim() == 3 and hyper.shape[0] == B and hyper.shape[1] == 4 and hyper.stride(2) == 1 and hyper.stride(0) == 4 * hyper.stride(1), "hyper_product: hyper")
+    _req(up.dim() == 2 and up.stride(1) == 1 and up.shape[0] >= B * P and masks.is_contiguous() and masks.numel() == B * 4 * P, "hyper_product: up / masks")
+    hip.check(hip.lib().marship_hyper_product(ptr(hyper), hyper.stride(1), ptr(up), up.stride(0), ptr(masks), B, P, C, stream()), "marship_hyper_product")
+
+
 def act_cast(x: torch.Tensor, out: torch.Tensor, act: int):
     _dev(x, out)
     _req(x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous() and out.numel() == x.numel(), "act_cast")

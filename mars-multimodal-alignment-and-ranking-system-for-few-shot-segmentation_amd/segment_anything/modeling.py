@@ -446,6 +446,9 @@ class MaskDecoder:
         td = self._buf("td", (B * Nt, C))
         hid = self._buf("hid", (B * Nt, self.layers[0]["lin2"].Kp))      # as wide as the padded K of lin2; pads stay zero
         pe2 = pe.view(B * Nt, C)
+        # kd = keys + key_pe and vd = keys in the compute dtype, made once per state of the image stream: here, and by
+        # the pass that applies norm4 at the end of each layer
+        ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens)
 
         def ln(x, wb, rows):
             ops.layernorm(x[:rows], wb[0], wb[1], x[:rows], 1e-5)
@@ -462,8 +465,6 @@ class MaskDecoder:
             ln(Q, L["n1"], B * Nt)
             # (2) tokens attend to the image
             ops.add_cast(Q, pe2, qd)
-            ops.add_cast(Kf, dense_pe_tokens, kd)
-            ops.add_cast(Kf, None, vd)
             self._attention(L["t2i"], "t2i", qd, kd, vd, B, Nt, Ni, Q, Q)
             ln(Q, L["n2"], B * Nt)
             # (3) MLP on the tokens
@@ -473,32 +474,23 @@ class MaskDecoder:
             ln(Q, L["n3"], B * Nt)
             # (4) the image attends to the tokens
             ops.add_cast(Q, pe2, qd)
-            ops.add_cast(Kf, dense_pe_tokens, kd)
             ops.add_cast(Q, None, td)
             self._attention(L["i2t"], "i2t", kd, qd, td, B, Ni, Nt, Kf, Kf)
-            ln(Kf, L["n4"], B * Ni)
+            ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens, norm=L["n4"], eps=1e-5,
+                              write_back=i + 1 < len(self.layers))        # (nothing reads the f32 stream after the last layer)
         ops.add_cast(Q, pe2, qd)
-        ops.add_cast(Kf, dense_pe_tokens, kd)
-        ops.add_cast(Kf, None, vd)
         self._attention(self.final, "fin", qd, kd, vd, B, Nt, Ni, Q, Q)
         ln(Q, self.nf, B * Nt)
         hs = Q.view(B, Nt, C)
         # upscaling: ConvT(2,2) -> LayerNorm2d -> GELU -> ConvT(2,2) -> GELU, written straight into the
         # pixel-shuffled layout: one batched GEMM per output-row parity (batch = (prompt, input row))
         C4, C8 = C // 4, C // 8
-        ops.add_cast(Kf, None, kd)
         u1 = self._buf("u1", (B * 4 * Ni, C4), f32)
         for dy in (0, 1):
-            ops.gemm(kd, self.up0[dy].w, u1, G, 2 * C4, self.up0[dy].Kp, lda=C, ldb=self.up0[dy].Kp, ldc=2 * C4, c_off=dy * G * 2 * C4,
+            ops.gemm(vd, self.up0[dy].w, u1, G, 2 * C4, self.up0[dy].Kp, lda=C, ldb=self.up0[dy].Kp, ldc=2 * C4, c_off=dy * G * 2 * C4,
                      nb0=B * G, sA=(G * C, 0), sC=(2 * G * 2 * C4, 0), bias=self.up0[dy].b)
-        ops.layernorm(u1, self.up_ln[0], self.up_ln[1], u1, 1e-6)
-        u1d = self._buf("u1d", (B * 4 * Ni, _pad_to(C4, 64)))
-        if u1d.shape[1] == C4:
-            ops.act_cast(u1, u1d, 1)
-        else:
-            tmp = self._buf("u1g", (B * 4 * Ni, C4))
-            ops.act_cast(u1, tmp, 1)
-            u1d[:, :C4] = tmp
+        u1d = self._buf("u1d", (B * 4 * Ni, _pad_to(C4, 64)))              # (pad columns stay zero)
+        ops.layernorm_act_rows(u1, self.up_ln[0], self.up_ln[1], u1d, 1e-6, 1)
         G2 = 2 * G
         u2 = self._buf("u2", (B * 16 * Ni, C8), f32)
         for dy in (0, 1):
@@ -524,12 +516,15 @@ class MaskDecoder:
         iou = cur
         # masks[b, m, pixel] = hyper[b, m, :] . upscaled[b, pixel, :]   (f32 product, K = C/8)
         P4 = 16 * Ni
+        masks = self._buf("masks", (B, 4, P4), f32)
+        if C8 <= 64 and C8 % 4 == 0 and B <= 65535:
+            ops.hyper_product(hyper, u2, masks, B, P4, C8)
+            return masks.view(B, 4, 4 * G, 4 * G), iou
         if Kh != C8:
             u2p = self._buf("u2p", (B * P4, Kh), f32)
             u2p[:, :C8] = u2
         else:
             u2p = u2
-        masks = self._buf("masks", (B, 4, P4), f32)
         ops.gemm(hyper, u2p, masks, 4, P4, Kh, lda=Kh, ldb=Kh, ldc=P4, nb0=B, sA=(4 * Kh, 0), sB=(P4 * Kh, 0), sC=(4 * P4, 0))
         return masks.view(B, 4, 4 * G, 4 * G), iou
 

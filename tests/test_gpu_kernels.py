@@ -1031,3 +1031,74 @@ def test_softmax_bias_rows_and_relpos(pkg, cuda, B, H, gw, hd, hdp):
     P = torch.empty(B * H * T, Tp, device=cuda)
     ops.softmax_bias_rows(S.view(B * H, T, Tp), P.view(B * H, T, Tp), B * H * T, T)
     assert float((P[:, :T] - torch.softmax(S[:, :T], -1)).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------ mask decoder: small-head attention and fused row passes
+@pytest.mark.parametrize("B,H,hd,Tq,Tk", [(5, 8, 32, 7, 7), (3, 8, 16, 7, 300), (3, 8, 16, 300, 7), (2, 4, 32, 9, 1000), (2, 4, 32, 1000, 9),
+                                          (1, 1, 16, 1, 16), (70, 8, 16, 16, 4096)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_small_matches_torch(pkg, cuda, B, H, hd, Tq, Tk, dtype):
+    """softmax(q k^T * scale) v on 16- and 32-wide heads with at most 16 tokens on one side, row-strided operands."""
+    W = H * hd
+    q = _rand((B * Tq, W), 1, cuda).to(dtype)
+    k = _rand((B * Tk, W), 2, cuda).to(dtype)
+    v = _rand((B * Tk, W), 3, cuda).to(dtype)
+    out = torch.full((B * Tq, W + 64), float("nan"), device=cuda, dtype=dtype)
+    scale = 1.0 / math.sqrt(hd)
+    pkg.ops.attn_small(q, k, v, out, B, H, hd, Tq, Tk, scale)
+    qh = q.double().view(B, Tq, H, hd).transpose(1, 2)
+    kh = k.double().view(B, Tk, H, hd).transpose(1, 2)
+    vh = v.double().view(B, Tk, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).transpose(1, 2).reshape(B * Tq, W)
+    got = out[:, :W].double()
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2          # bf16: one rounding of the result (2^-8 relative, |out| <~ 3)
+    assert float((got - ref).abs().max()) <= tol
+    assert bool(torch.isnan(out[:, W:].float()).all())        # columns beyond the heads are not written
+
+
+@pytest.mark.parametrize("rows,D,add_rows", [(12, 256, 4), (4096 * 3, 256, 4096), (7, 64, 7), (10, 1024, 5), (9, 2048, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("norm", [False, True])
+def test_stream_copies(pkg, cuda, rows, D, add_rows, dtype, norm):
+    x = _rand((rows, D), 4, cuda) + 0.5
+    add = _rand((add_rows, D), 5, cuda)
+    w, b = _rand((D,), 6, cuda) + 1.0, _rand((D,), 7, cuda)
+    y = F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5) if norm else x.double()
+    c0 = torch.empty(rows, D, device=cuda, dtype=dtype); c1 = torch.empty_like(c0)
+    x_in = x.clone()
+    pkg.ops.stream_copies(x_in, c0, c1, add=add, norm=(w, b) if norm else None, eps=1e-5)
+    tol = 1e-5 if dtype == torch.float32 else 4e-2
+    ref0 = y + add.double().repeat(rows // add_rows, 1)
+    assert float((c1.double() - y).abs().max()) <= tol
+    assert float((c0.double() - ref0).abs().max()) <= tol
+    assert float((x_in.double() - y).abs().max()) <= 1e-5     # the f32 stream holds the normalised rows (or is untouched)
+    # one copy only, no write-back
+    x2 = x.clone(); only = torch.empty_like(c0)
+    pkg.ops.stream_copies(x2, None, only, norm=(w, b) if norm else None, write_back=False)
+    assert torch.equal(x2, x) and torch.equal(only, c1)
+
+
+@pytest.mark.parametrize("rows,D,ldo", [(100, 64, 64), (16385, 64, 64), (33, 40, 64), (5, 256, 256), (17, 128, 192)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 1])
+def test_layernorm_act_rows(pkg, cuda, rows, D, ldo, dtype, act):
+    x = _rand((rows, D), 8, cuda) * 2 + 0.3
+    w, b = _rand((D,), 9, cuda) + 1.0, _rand((D,), 10, cuda)
+    out = torch.full((rows, ldo), 7.0, device=cuda, dtype=dtype)
+    pkg.ops.layernorm_act_rows(x, w, b, out, 1e-6, act)
+    ref = F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
+    if act:
+        ref = F.gelu(ref)
+    tol = 1e-5 if dtype == torch.float32 else 4e-2
+    assert float((out[:, :D].double() - ref).abs().max()) <= tol
+    assert bool((out[:, D:] == 7.0).all())
+
+
+@pytest.mark.parametrize("B,P,C,ldh,ldu", [(3, 1000, 32, 32, 32), (2, 65536, 32, 32, 32), (5, 257, 64, 64, 64), (4, 300, 20, 32, 24)])
+def test_hyper_product(pkg, cuda, B, P, C, ldh, ldu):
+    hyper = _rand((B, 4, ldh), 11, cuda)
+    up = _rand((B * P, ldu), 12, cuda)
+    masks = torch.full((B, 4, P), float("nan"), device=cuda)
+    pkg.ops.hyper_product(hyper, up, masks, B, P, C)
+    ref = hyper[:, :, :C].double() @ up[:, :C].double().view(B, P, C).transpose(1, 2)
+    assert float((masks.double() - ref).abs().max()) <= 1e-4
