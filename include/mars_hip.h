@@ -275,9 +275,11 @@ int marship_gather_rows(const void* src, int64_t ld_src, int src_col, const int3
  * out[b, i, h*hd + d] = sum_j softmax_j(scale * q[b, i, h, :] . k[b, j, h, :]) v[b, j, h, d] on UNPADDED heads of 16 or 32
  * dims, for products where one side is a handful of tokens: Tk <= 16 (image -> tokens, tokens -> tokens; any Tq) or
  * Tq <= 16 (tokens -> image; any Tk).  q [B*Tq, ldq], k / v [B*Tk, ld], out [B*Tq, ldo], head h at column h*hd; H a power of
- * two; rows 16-byte aligned; f32 accumulation; dtype 0 = f32, 1 = bf16 (all four tensors). */
+ * two; rows 16-byte aligned; f32 accumulation; dtype 0 = f32, 1 = bf16 (all four tensors).  `shared` bit 0: q holds one
+ * set of Tq rows that every prompt uses (the image-side queries of the first layer, where the image stream is still the
+ * same for every prompt); bit 1: the same for k and v (Tk rows). */
 int marship_attn_small(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                       void* out, int64_t ldo, int B, int H, int hd, int Tq, int Tk, float scale, int dtype,
+                       void* out, int64_t ldo, int B, int H, int hd, int Tq, int Tk, float scale, int shared, int dtype,
                        void* stream);
 /* Decomposed relative-position terms (image_encoder.py:325-361): q is read from the packed qkv
  * buffer (row b*T+t, column head*hdp+d, d < hd); Rh [gh, Hk, hd] and Rw [gw, Wk, hd] are the

@@ -56,21 +56,21 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, const float (&x)[HD
 template <typename T, int HD, int TKMAX>
 __global__ __launch_bounds__(256) void attn_few_keys_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
                                                             const T* __restrict__ v, int64_t ldv, T* __restrict__ out, int64_t ldo, int H,
-                                                            int Tq, int Tk, float scale) {
+                                                            int Tq, int Tk, float scale, int qb, int kb) {
     extern __shared__ float sm[];
-    const int W = H * HD, b = blockIdx.y, tid = threadIdx.x;
+    const int W = H * HD, b = blockIdx.y, tid = threadIdx.x;          // qb / kb: rows a prompt of q / of k and v (0: one set for all)
     float* sK = sm;
     float* sV = sm + TKMAX * W;
     for (int i = tid; i < Tk * W; i += 256) {
         const int j = i / W, c = i - j * W;
-        sK[i] = (float)k[((int64_t)b * Tk + j) * ldk + c];
-        sV[i] = (float)v[((int64_t)b * Tk + j) * ldv + c];
+        sK[i] = (float)k[((int64_t)b * kb + j) * ldk + c];
+        sV[i] = (float)v[((int64_t)b * kb + j) * ldv + c];
     }
     __syncthreads();
     const int row = blockIdx.x * (256 / H) + tid / H, h = tid % H;
     if (row >= Tq || tid >= (256 / H) * H) return;
     float qv[HD];
-    load_row<T, HD>(q + ((int64_t)b * Tq + row) * ldq + h * HD, qv);
+    load_row<T, HD>(q + ((int64_t)b * qb + row) * ldq + h * HD, qv);
     float s[TKMAX];
     float m = -INFINITY;
 #pragma unroll
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(256) void attn_few_keys_kernel(const T* __restrict_
 template <typename T, int HD, int TQ>
 __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
                                                                const T* __restrict__ v, int64_t ldv, T* __restrict__ out, int64_t ldo, int H,
-                                                               int Tq, int Tk, float scale, int q0, int nq) {
+                                                               int Tq, int Tk, float scale, int q0, int nq, int qb, int kb) {
     extern __shared__ float sm[];
     const int W = H * HD, b = blockIdx.x, tid = threadIdx.x;
     float* sQ = sm;                                   // [TQ][W]
     float* sP = sm + TQ * W;                          // [4][H][TQ][HD + 2]
     for (int i = tid; i < nq * W; i += 256) {
         const int j = i / W, c = i - j * W;
-        sQ[i] = (float)q[((int64_t)b * Tq + q0 + j) * ldq + c] * scale;
+        sQ[i] = (float)q[((int64_t)b * qb + q0 + j) * ldq + c] * scale;
     }
     __syncthreads();
     const int h = tid % H, kl = tid / H, nkl = 256 / H;          // key lanes: keys kl, kl + nkl, ...
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restri
     }
     for (int key = kl; key < Tk; key += nkl) {
         float kv[HD], vv[HD];
-        load_row<T, HD>(k + ((int64_t)b * Tk + key) * ldk + h * HD, kv);
-        load_row<T, HD>(v + ((int64_t)b * Tk + key) * ldv + h * HD, vv);
+        load_row<T, HD>(k + ((int64_t)b * kb + key) * ldk + h * HD, kv);
+        load_row<T, HD>(v + ((int64_t)b * kb + key) * ldv + h * HD, vv);
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
             if (j < nq) {
@@ -195,14 +195,14 @@ __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restri
 
 template <typename T, int HD>
 int launch_small(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, int B, int H,
-                 int Tq, int Tk, float scale, hipStream_t s) {
-    const int W = H * HD;
+                 int Tq, int Tk, float scale, int shared, hipStream_t s) {
+    const int W = H * HD, qb = (shared & 1) ? 0 : Tq, kb = (shared & 2) ? 0 : Tk;
     if (Tk <= 16) {
         const dim3 grid((unsigned)((Tq + 256 / H - 1) / (256 / H)), (unsigned)B), block(256);
         if (Tk <= 8) hipLaunchKernelGGL((attn_few_keys_kernel<T, HD, 8>), grid, block, 2 * 8 * W * sizeof(float), s, (const T*)q, ldq, (const T*)k, ldk,
-                                        (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale);
+                                        (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale, qb, kb);
         else hipLaunchKernelGGL((attn_few_keys_kernel<T, HD, 16>), grid, block, 2 * 16 * W * sizeof(float), s, (const T*)q, ldq, (const T*)k, ldk,
-                                (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale);
+                                (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale, qb, kb);
         MARS_LAUNCH_CHECK();
         return 0;
     }
@@ -211,7 +211,7 @@ int launch_small(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     for (int q0 = 0; q0 < Tq; q0 += TQ) {
         const int nq = Tq - q0 < TQ ? Tq - q0 : TQ;
         hipLaunchKernelGGL((attn_few_queries_kernel<T, HD, TQ>), dim3((unsigned)B), dim3(256), shm, s, (const T*)q, ldq, (const T*)k, ldk,
-                           (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale, q0, nq);
+                           (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale, q0, nq, qb, kb);
         MARS_LAUNCH_CHECK();
     }
     return 0;
@@ -220,21 +220,22 @@ int launch_small(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
 }  // namespace
 
 extern "C" int marship_attn_small(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out,
-                                  int64_t ldo, int B, int H, int hd, int Tq, int Tk, float scale, int dtype, void* stream) {
+                                  int64_t ldo, int B, int H, int hd, int Tq, int Tk, float scale, int shared, int dtype, void* stream) {
     MARS_CHECK(q && k && v && out, "attn_small: null pointer");
     MARS_CHECK(B > 0 && B <= 65535 && Tq > 0 && Tk > 0, "attn_small: bad shape B=%d Tq=%d Tk=%d", B, Tq, Tk);
     MARS_CHECK(H == 1 || H == 2 || H == 4 || H == 8 || H == 16 || H == 32 || H == 64, "attn_small: %d heads (a power of two up to 64)", H);
     MARS_CHECK(hd == 16 || hd == 32, "attn_small: head dim %d (16 or 32)", hd);
     MARS_CHECK(Tk <= 16 || Tq <= 16, "attn_small: one side must have at most 16 tokens (Tq=%d, Tk=%d)", Tq, Tk);
     MARS_CHECK(dtype == 0 || dtype == 1, "attn_small: dtype %d", dtype);
+    MARS_CHECK(shared >= 0 && shared <= 3, "attn_small: shared %d (bit 0: q, bit 1: k and v)", shared);
     const int W = H * hd, es = dtype == 1 ? 2 : 4;
     MARS_CHECK(ldq >= W && ldk >= W && ldv >= W && ldo >= W, "attn_small: a row stride is smaller than heads x head dim");
     MARS_CHECK((ldq * es) % 16 == 0 && (ldk * es) % 16 == 0 && (ldv * es) % 16 == 0 && (ldo * es) % 16 == 0 &&
                ((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "attn_small: rows must be 16-byte aligned");
     MARS_CHECK((size_t)2 * 16 * W * sizeof(float) <= 64 * 1024, "attn_small: %d x %d is too wide for the LDS copy of K and V", H, hd);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == 1) return hd == 16 ? launch_small<__bf16, 16>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, s)
-                                    : launch_small<__bf16, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, s);
-    return hd == 16 ? launch_small<float, 16>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, s)
-                    : launch_small<float, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, s);
+    if (dtype == 1) return hd == 16 ? launch_small<__bf16, 16>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, shared, s)
+                                    : launch_small<__bf16, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, shared, s);
+    return hd == 16 ? launch_small<float, 16>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, shared, s)
+                    : launch_small<float, 32>(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Tq, Tk, scale, shared, s);
 }

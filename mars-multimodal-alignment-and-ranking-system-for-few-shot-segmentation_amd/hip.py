@@ -47,7 +47,7 @@ _SIGNATURES = {
     "marship_ln_finish": [_P, _I, _I, _I, _F, _P, _P, _F, _P],
     "marship_row_stats": [_P, _L, _I, _I, _F, _P, _P, _L, _P, _P, _F, _P],
     "marship_im2col": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _I, _P],
-    "marship_attn_small": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _P],
+    "marship_attn_small": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "marship_embed_tokens": [_P, _I, _P, _P, _P, _L, _I, _I, _P],
     "marship_write_prefix_tokens": [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     "marship_transpose": [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _I, _I, _P],

@@ -615,15 +615,17 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor, *, src_
                                             dt(src), stream()), "marship_gather_rows")
 
 
-def attn_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, B: int, H: int, hd: int, Tq: int, Tk: int, scale: float):
+def attn_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, B: int, H: int, hd: int, Tq: int, Tk: int, scale: float,
+               q_shared: bool = False, kv_shared: bool = False):
     """Attention on unpadded heads of 16 or 32 dims where one side has at most 16 tokens: q [B*Tq, >= H*hd], k / v [B*Tk, ...],
-    out [B*Tq, ...], rows may be wider than H*hd (row stride = stride(0))."""
+    out [B*Tq, ...], rows may be wider than H*hd (row stride = stride(0)).  ``q_shared`` / ``kv_shared``: that operand holds one
+    set of rows ([Tq, ...] / [Tk, ...]) used by every prompt."""
     _dev(q, k, v, out)
     _req(q.dtype == k.dtype == v.dtype == out.dtype and q.dtype in (torch.float32, torch.bfloat16), "attn_small: one dtype, f32 or bf16")
-    for t, rows in ((q, B * Tq), (k, B * Tk), (v, B * Tk), (out, B * Tq)):
+    for t, rows in ((q, Tq if q_shared else B * Tq), (k, Tk if kv_shared else B * Tk), (v, Tk if kv_shared else B * Tk), (out, B * Tq)):
         _req(t.dim() == 2 and t.stride(1) == 1 and t.shape[0] >= rows and t.shape[1] >= H * hd, "attn_small: operand layout")
     hip.check(hip.lib().marship_attn_small(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(out), out.stride(0),
-                                           B, H, hd, Tq, Tk, scale, dt(q), stream()), "marship_attn_small")
+                                           B, H, hd, Tq, Tk, scale, int(q_shared) | 2 * int(kv_shared), dt(q), stream()), "marship_attn_small")
 
 
 def relpos_bias(qkv: torch.Tensor, B: int, T: int, H: int, hd: int, hdp: int, gw: int, Rh: torch.Tensor, Rw: torch.Tensor,

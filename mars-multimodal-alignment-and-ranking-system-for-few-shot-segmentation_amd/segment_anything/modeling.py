@@ -397,18 +397,29 @@ class MaskDecoder:
             b = self._bufs[key] = torch.zeros(*shape, dtype=dtype, device=self.device)
         return b
 
-    def _attention(self, A: _DecAttn, tag: str, q_in, k_in, v_in, nb: int, Tq: int, Tk: int, out: torch.Tensor, residual):
-        """transformer.py:218-240: q_in [nb*Tq, C], k_in / v_in [nb*Tk, C] in the compute dtype -> out f32 (+ residual)."""
+    def _attention(self, A: _DecAttn, tag: str, q_in, k_in, v_in, nb: int, Tq: int, Tk: int, out: torch.Tensor, residual,
+                   q_shared: bool = False, kv_shared: bool = False):
+        """transformer.py:218-240: q_in [nb*Tq, C], k_in / v_in [nb*Tk, C] in the compute dtype -> out f32 (+ residual).
+        ``q_shared``: q_in and residual hold one set of Tq rows for every prompt; ``kv_shared``: k_in / v_in one set of Tk rows
+        (the image side of the first layer: projected once, not once a prompt)."""
         if A.small and (Tk <= 16 or Tq <= 16):
             W = A.H * A.hd
-            q = self._buf(tag + "qs", (nb * Tq, W)); k = self._buf(tag + "ks", (nb * Tk, W)); v = self._buf(tag + "vs", (nb * Tk, W))
+            nq, nk = (1 if q_shared else nb), (1 if kv_shared else nb)
+            q = self._buf(tag + "qs", (nq * Tq, W)); k = self._buf(tag + "ks", (nk * Tk, W)); v = self._buf(tag + "vs", (nk * Tk, W))
             ops.linear(q_in, A.qs.w, q, bias=A.qs.b)
             ops.linear(k_in, A.ks.w, k, bias=A.ks.b)
             ops.linear(v_in, A.vs.w, v, bias=A.vs.b)
-            o = self._buf(tag + "os", (nb * Tq, _pad_to(W, 64)))         # (K of the output projection, padded like its weight)
-            ops.attn_small(q, k, v, o, nb, A.H, A.hd, Tq, Tk, 1.0 / math.sqrt(A.hd))
-            ops.linear(o, A.os.w, out, bias=A.os.b, residual=residual)
+            Wp = _pad_to(W, 64)
+            o = self._buf(tag + "os", (nb * Tq, Wp))                     # (K of the output projection, padded like its weight)
+            ops.attn_small(q, k, v, o, nb, A.H, A.hd, Tq, Tk, 1.0 / math.sqrt(A.hd), q_shared=q_shared, kv_shared=kv_shared)
+            if q_shared:                                                 # one product a prompt: the residual rows repeat
+                N = A.os.w.shape[0]
+                ops.gemm(o, A.os.w, out, Tq, N, Wp, lda=Wp, ldb=A.os.w.stride(0), ldc=out.stride(0), nb0=nb, sA=(Tq * Wp, 0),
+                         sC=(Tq * out.stride(0), 0), bias=A.os.b, residual=residual, ldr=residual.stride(0), sR=(0, 0))
+            else:
+                ops.linear(o, A.os.w, out, bias=A.os.b, residual=residual)
             return
+        assert not (q_shared or kv_shared)
         W = A.H * A.hdp
         q = self._buf(tag + "q", (nb * Tq, W)); k = self._buf(tag + "k", (nb * Tk, W)); v = self._buf(tag + "v", (nb * Tk, W))
         ops.linear(q_in, A.q.w, q, bias=A.q.b)
@@ -436,19 +447,29 @@ class MaskDecoder:
         Q = self._buf("Q", (B * Nt, C), f32); Q.copy_(tokens.view(B * Nt, C))
         # src = image embedding + dense prompt embedding, one copy per prompt (:126-127)
         Kf = self._buf("K", (B * Ni, C), f32)
+        qd, kd, vd = self._buf("qd", (B * Nt, C)), self._buf("kd", (B * Ni, C)), self._buf("vd", (B * Ni, C))
+        # Without mask prompts the image stream entering the first layer is the same for every prompt: its key, value and
+        # query projections are made once, and the stream only becomes per-prompt when the first layer's image -> token
+        # attention writes it.
+        first = self.layers[0] if self.layers else None
+        share0 = dense_tokens is None and first is not None and first["t2i"].small and first["i2t"].small and Nt <= 16
         if dense_tokens is None:
             src0 = self._buf("src0", (Ni, C), f32)
             ops.add_cast(feats_tokens, no_mask.view(1, C), src0)
-            Kf.view(B, Ni, C).copy_(src0)
+            if share0:
+                kd0, vd0 = self._buf("kd0", (Ni, C)), self._buf("vd0", (Ni, C))
+                ops.stream_copies(src0, kd0, vd0, add=dense_pe_tokens)
+            else:
+                Kf.view(B, Ni, C).copy_(src0)
         else:
             ops.add_cast(dense_tokens.reshape(B * Ni, C).contiguous(), feats_tokens.contiguous(), Kf)
-        qd, kd, vd = self._buf("qd", (B * Nt, C)), self._buf("kd", (B * Ni, C)), self._buf("vd", (B * Ni, C))
         td = self._buf("td", (B * Nt, C))
         hid = self._buf("hid", (B * Nt, self.layers[0]["lin2"].Kp))      # as wide as the padded K of lin2; pads stay zero
         pe2 = pe.view(B * Nt, C)
         # kd = keys + key_pe and vd = keys in the compute dtype, made once per state of the image stream: here, and by
         # the pass that applies norm4 at the end of each layer
-        ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens)
+        if not share0:
+            ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens)
 
         def ln(x, wb, rows):
             ops.layernorm(x[:rows], wb[0], wb[1], x[:rows], 1e-5)
@@ -465,7 +486,10 @@ class MaskDecoder:
             ln(Q, L["n1"], B * Nt)
             # (2) tokens attend to the image
             ops.add_cast(Q, pe2, qd)
-            self._attention(L["t2i"], "t2i", qd, kd, vd, B, Nt, Ni, Q, Q)
+            if share0 and i == 0:
+                self._attention(L["t2i"], "t2i", qd, kd0, vd0, B, Nt, Ni, Q, Q, kv_shared=True)
+            else:
+                self._attention(L["t2i"], "t2i", qd, kd, vd, B, Nt, Ni, Q, Q)
             ln(Q, L["n2"], B * Nt)
             # (3) MLP on the tokens
             ops.add_cast(Q, None, qd)
@@ -475,7 +499,10 @@ class MaskDecoder:
             # (4) the image attends to the tokens
             ops.add_cast(Q, pe2, qd)
             ops.add_cast(Q, None, td)
-            self._attention(L["i2t"], "i2t", kd, qd, td, B, Ni, Nt, Kf, Kf)
+            if share0 and i == 0:
+                self._attention(L["i2t"], "i2t", kd0, qd, td, B, Ni, Nt, Kf, src0, q_shared=True)
+            else:
+                self._attention(L["i2t"], "i2t", kd, qd, td, B, Ni, Nt, Kf, Kf)
             ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens, norm=L["n4"], eps=1e-5,
                               write_back=i + 1 < len(self.layers))        # (nothing reads the f32 stream after the last layer)
         ops.add_cast(Q, pe2, qd)

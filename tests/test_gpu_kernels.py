@@ -1054,6 +1054,14 @@ def test_attn_small_matches_torch(pkg, cuda, B, H, hd, Tq, Tk, dtype):
     tol = 2e-5 if dtype == torch.float32 else 1.6e-2          # bf16: one rounding of the result (2^-8 relative, |out| <~ 3)
     assert float((got - ref).abs().max()) <= tol
     assert bool(torch.isnan(out[:, W:].float()).all())        # columns beyond the heads are not written
+    # one set of queries, or of keys and values, for every prompt
+    for qs, ks in ((True, False), (False, True)):
+        out2 = torch.empty(B * Tq, W, device=cuda, dtype=dtype)
+        pkg.ops.attn_small(q[:Tq] if qs else q, k[:Tk] if ks else k, v[:Tk] if ks else v, out2, B, H, hd, Tq, Tk, scale, q_shared=qs, kv_shared=ks)
+        q2 = qh[:1].expand(B, -1, -1, -1) if qs else qh
+        k2, v2 = (kh[:1].expand(B, -1, -1, -1), vh[:1].expand(B, -1, -1, -1)) if ks else (kh, vh)
+        ref2 = (torch.softmax(q2 @ k2.transpose(-1, -2) * scale, -1) @ v2).transpose(1, 2).reshape(B * Tq, W)
+        assert float((out2.double() - ref2).abs().max()) <= tol
 
 
 @pytest.mark.parametrize("rows,D,add_rows", [(12, 256, 4), (4096 * 3, 256, 4096), (7, 64, 7), (10, 1024, 5), (9, 2048, 1)])
