@@ -321,6 +321,18 @@ int marship_stream_copies(const float* x, const float* w, const float* b, float 
  * ldo: LayerNorm2d + GELU of the output upscaling (mask_decoder.py:53-59, common.py:31-43). */
 int marship_layernorm_act_rows(const float* x, const float* w, const float* b, float eps, void* out, int64_t ldo,
                                int64_t rows, int D, int act, int out_dtype, void* stream);
+/* The output upscaling at the shipped decoder width (256 -> 64 -> 32 channels), bf16 operands, without the f32 tensors
+ * between its stages (mask_decoder.py:53-59,136-143).
+ * marship_sam_upscale_ln_gelu: ConvTranspose2d(256, 64, 2, 2) + LayerNorm2d(eps) + GELU.  x bf16 [prompts*G*G, ldx] token-major;
+ *   w0 bf16 [32][256][8]: entry (kc, r) holds W[r][8kc .. 8kc+7] with W[(dy, dx, c)][k] = weight[k, c, dy, dx]; prm f32 [3][64] =
+ *   convolution bias, LayerNorm weight, LayerNorm bias; out bf16 [prompts*4*G*G, ldo], pixels row-major on the 2G x 2G grid.
+ * marship_sam_upscale_masks: ConvTranspose2d(64, 32, 2, 2) + GELU + (hyper_in @ upscaled).  u = the result above
+ *   (G2 = 2G, a multiple of 32); w3 bf16 [(dy, dx, c) = 128][64]; bias f32 [32]; hyper f32 [prompts*4, ldh]; masks f32
+ *   [prompts, 4, 2*G2, 2*G2].  GELU in both is the erf form evaluated to 1.5e-7 absolute. */
+int marship_sam_upscale_ln_gelu(const void* x, int64_t ldx, const void* w0, const float* prm, float eps, void* out,
+                                int64_t ldo, int64_t prompts, int G, void* stream);
+int marship_sam_upscale_masks(const void* u, int64_t ldu, const void* w3, const float* bias, const float* hyper,
+                              int64_t ldh, float* masks, int64_t prompts, int G2, void* stream);
 /* masks[b, m, p] = sum_c hyper[b, m, c] * up[b*P + p, c], four masks a prompt, C <= 64 channels (mask_decoder.py:141-143:
  * hyper_in @ upscaled_embedding); hyper f32 [B*4, ldh], up f32 [B*P, ldu], masks f32 [B, 4, P]. */
 int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int64_t ldu, float* masks, int B,

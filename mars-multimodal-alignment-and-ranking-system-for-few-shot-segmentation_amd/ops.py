@@ -726,6 +726,32 @@ def layernorm_act_rows(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: t
               "marship_layernorm_act_rows")
 
 
+def sam_upscale_ln_gelu(x: torch.Tensor, w0: torch.Tensor, prm: torch.Tensor, out: torch.Tensor, prompts: int, G: int, eps: float = 1e-6):
+    """ConvTranspose2d(256, 64, 2, 2) + LayerNorm2d + GELU: x bf16 [prompts*G*G, >= 256] -> out bf16 [prompts*4*G*G, >= 64];
+    w0 bf16 [32, 256, 8] (runs of eight K, run-major), prm f32 [3, 64]."""
+    _dev(x, w0, prm, out)
+    _req(x.dtype == out.dtype == w0.dtype == torch.bfloat16 and prm.dtype == torch.float32, "sam_upscale_ln_gelu: dtypes")
+    _req(x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1 and x.shape[0] >= prompts * G * G and x.shape[1] >= 256
+         and out.shape[0] >= prompts * 4 * G * G and out.shape[1] >= 64, "sam_upscale_ln_gelu: activations")
+    _req(w0.is_contiguous() and w0.numel() == 256 * 256 and prm.is_contiguous() and prm.numel() == 192, "sam_upscale_ln_gelu: parameters")
+    hip.check(hip.lib().marship_sam_upscale_ln_gelu(ptr(x), x.stride(0), ptr(w0), ptr(prm), eps, ptr(out), out.stride(0), prompts, G, stream()),
+              "marship_sam_upscale_ln_gelu")
+
+
+def sam_upscale_masks(u: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, hyper: torch.Tensor, masks: torch.Tensor, prompts: int, G2: int):
+    """ConvTranspose2d(64, 32, 2, 2) + GELU + product with the prompt's four hypernetwork vectors: u bf16 [prompts*G2*G2, >= 64],
+    w3 bf16 [128, 64], bias f32 [32], hyper f32 [prompts, 4, >= 32] -> masks f32 [prompts, 4, 2*G2, 2*G2]."""
+    _dev(u, w3, bias, hyper, masks)
+    _req(u.dtype == w3.dtype == torch.bfloat16 and bias.dtype == hyper.dtype == masks.dtype == torch.float32, "sam_upscale_masks: dtypes")
+    _req(u.dim() == 2 and u.stride(1) == 1 and u.shape[0] >= prompts * G2 * G2 and u.shape[1] >= 64, "sam_upscale_masks: u")
+    _req(w3.is_contiguous() and w3.numel() == 128 * 64 and bias.is_contiguous() and bias.numel() == 32, "sam_upscale_masks: parameters")
+    _req(hyper.dim() == 3 and hyper.shape[0] >= prompts and hyper.shape[1] == 4 and hyper.shape[2] >= 32 and hyper.stride(2) == 1
+         and hyper.stride(0) == 4 * hyper.stride(1), "sam_upscale_masks: hyper")
+    _req(masks.is_contiguous() and masks.numel() == prompts * 16 * G2 * G2, "sam_upscale_masks: masks")
+    hip.check(hip.lib().marship_sam_upscale_masks(ptr(u), u.stride(0), ptr(w3), ptr(bias), ptr(hyper), hyper.stride(1), ptr(masks), prompts, G2,
+                                                  stream()), "marship_sam_upscale_masks")
+
+
 def hyper_product(hyper: torch.Tensor, up: torch.Tensor, masks: torch.Tensor, B: int, P: int, C: int):
     """masks[b, m, p] = hyper[b, m, :C] . up[b*P + p, :C]; hyper f32 [B, 4, >= C], up f32 [B*P, >= C], masks f32 [B, 4, P]."""
     _dev(hyper, up, masks)

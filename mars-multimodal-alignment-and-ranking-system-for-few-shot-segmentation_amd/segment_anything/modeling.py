@@ -382,6 +382,17 @@ class MaskDecoder:
         self.up0 = convT("mask_decoder.output_upscaling.0")
         self.up_ln = ln("mask_decoder.output_upscaling.1")
         self.up3 = convT("mask_decoder.output_upscaling.3")
+        # At the shipped width (256 -> 64 -> 32) in bf16 the upscaling runs as two fused kernels (ops.sam_upscale_*):
+        # whole weights with rows (dy, dx, channel); the first in runs of eight K, run-major, as its kernel keeps it in LDS.
+        # MARS_SAM_FUSED_UPSCALE=0 keeps the product-per-stage form.
+        self.fused_up = C == 256 and dtype == torch.bfloat16 and os.environ.get("MARS_SAM_FUSED_UPSCALE", "1") != "0"
+        if self.fused_up:
+            w0 = sd["mask_decoder.output_upscaling.0.weight"].float().permute(2, 3, 1, 0).reshape(256, 256)
+            self.up0_runs = w0.view(256, 32, 8).permute(1, 0, 2).contiguous().to(dev, torch.bfloat16)
+            self.up0_prm = torch.stack([sd["mask_decoder.output_upscaling.0.bias"].float(), sd["mask_decoder.output_upscaling.1.weight"].float(),
+                                        sd["mask_decoder.output_upscaling.1.bias"].float()]).contiguous().to(dev)
+            self.up3_rows = sd["mask_decoder.output_upscaling.3.weight"].float().permute(2, 3, 1, 0).reshape(128, 64).contiguous().to(dev, torch.bfloat16)
+            self.up3_bias = _dev_f32(sd["mask_decoder.output_upscaling.3.bias"], dev)
         self.hyper = [[Lin(sd[f"mask_decoder.output_hypernetworks_mlps.{i}.layers.{j}.weight"],
                            sd[f"mask_decoder.output_hypernetworks_mlps.{i}.layers.{j}.bias"], dtype, dev) for j in range(3)] for i in range(4)]
         self.iou = [Lin(sd[f"mask_decoder.iou_prediction_head.layers.{j}.weight"], sd[f"mask_decoder.iou_prediction_head.layers.{j}.bias"], dtype, dev)
@@ -512,17 +523,21 @@ class MaskDecoder:
         # upscaling: ConvT(2,2) -> LayerNorm2d -> GELU -> ConvT(2,2) -> GELU, written straight into the
         # pixel-shuffled layout: one batched GEMM per output-row parity (batch = (prompt, input row))
         C4, C8 = C // 4, C // 8
-        u1 = self._buf("u1", (B * 4 * Ni, C4), f32)
-        for dy in (0, 1):
-            ops.gemm(vd, self.up0[dy].w, u1, G, 2 * C4, self.up0[dy].Kp, lda=C, ldb=self.up0[dy].Kp, ldc=2 * C4, c_off=dy * G * 2 * C4,
-                     nb0=B * G, sA=(G * C, 0), sC=(2 * G * 2 * C4, 0), bias=self.up0[dy].b)
-        u1d = self._buf("u1d", (B * 4 * Ni, _pad_to(C4, 64)))              # (pad columns stay zero)
-        ops.layernorm_act_rows(u1, self.up_ln[0], self.up_ln[1], u1d, 1e-6, 1)
         G2 = 2 * G
-        u2 = self._buf("u2", (B * 16 * Ni, C8), f32)
-        for dy in (0, 1):
-            ops.gemm(u1d, self.up3[dy].w, u2, G2, 2 * C8, self.up3[dy].Kp, lda=u1d.shape[1], ldb=self.up3[dy].Kp, ldc=2 * C8,
-                     c_off=dy * G2 * 2 * C8, nb0=B * G2, sA=(G2 * u1d.shape[1], 0), sC=(2 * G2 * 2 * C8, 0), bias=self.up3[dy].b, act=1)
+        fused = self.fused_up and G2 % 32 == 0 and B <= 65535
+        u1d = self._buf("u1d", (B * 4 * Ni, _pad_to(C4, 64)))              # (pad columns stay zero)
+        if fused:
+            ops.sam_upscale_ln_gelu(vd, self.up0_runs, self.up0_prm, u1d, B, G, 1e-6)
+        else:
+            u1 = self._buf("u1", (B * 4 * Ni, C4), f32)
+            for dy in (0, 1):
+                ops.gemm(vd, self.up0[dy].w, u1, G, 2 * C4, self.up0[dy].Kp, lda=C, ldb=self.up0[dy].Kp, ldc=2 * C4, c_off=dy * G * 2 * C4,
+                         nb0=B * G, sA=(G * C, 0), sC=(2 * G * 2 * C4, 0), bias=self.up0[dy].b)
+            ops.layernorm_act_rows(u1, self.up_ln[0], self.up_ln[1], u1d, 1e-6, 1)
+            u2 = self._buf("u2", (B * 16 * Ni, C8), f32)
+            for dy in (0, 1):
+                ops.gemm(u1d, self.up3[dy].w, u2, G2, 2 * C8, self.up3[dy].Kp, lda=u1d.shape[1], ldb=self.up3[dy].Kp, ldc=2 * C8,
+                         c_off=dy * G2 * 2 * C8, nb0=B * G2, sA=(G2 * u1d.shape[1], 0), sC=(2 * G2 * 2 * C8, 0), bias=self.up3[dy].b, act=1)
         # hypernetwork MLPs on the four mask tokens, IoU head on the IoU token
         Kh = _pad_to(C8, 32)
         hyper = self._buf("hyper", (B, 4, Kh), f32)
@@ -544,6 +559,9 @@ class MaskDecoder:
         # masks[b, m, pixel] = hyper[b, m, :] . upscaled[b, pixel, :]   (f32 product, K = C/8)
         P4 = 16 * Ni
         masks = self._buf("masks", (B, 4, P4), f32)
+        if fused:
+            ops.sam_upscale_masks(u1d, self.up3_rows, self.up3_bias, hyper, masks, B, G2)
+            return masks.view(B, 4, 4 * G, 4 * G), iou
         if C8 <= 64 and C8 % 4 == 0 and B <= 65535:
             ops.hyper_product(hyper, u2, masks, B, P4, C8)
             return masks.view(B, 4, 4 * G, 4 * G), iou

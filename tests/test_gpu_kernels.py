@@ -1110,3 +1110,36 @@ def test_hyper_product(pkg, cuda, B, P, C, ldh, ldu):
     pkg.ops.hyper_product(hyper, up, masks, B, P, C)
     ref = hyper[:, :, :C].double() @ up[:, :C].double().view(B, P, C).transpose(1, 2)
     assert float((masks.double() - ref).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("prompts,G", [(3, 32), (1, 8), (4, 12), (2, 64)])
+def test_sam_upscale_ln_gelu_matches_torch(pkg, cuda, prompts, G):
+    """ConvTranspose2d(256, 64, 2, 2) + LayerNorm2d + GELU as one kernel against the torch layers on the same bf16 operands."""
+    x = _rand((prompts * G * G, 256), 21, cuda).to(torch.bfloat16)
+    wt = (_rand((256, 64, 2, 2), 22, cuda) * 0.08).to(torch.bfloat16)
+    cb, lw, lb = _rand((64,), 23, cuda) * 0.2, _rand((64,), 24, cuda) * 0.3 + 1.0, _rand((64,), 25, cuda) * 0.2
+    rows = wt.float().permute(2, 3, 1, 0).reshape(256, 256)
+    runs = rows.view(256, 32, 8).permute(1, 0, 2).contiguous().to(torch.bfloat16)
+    out = torch.full((prompts * 4 * G * G, 64), float("nan"), device=cuda, dtype=torch.bfloat16)
+    pkg.ops.sam_upscale_ln_gelu(x, runs, torch.stack([cb, lw, lb]).contiguous(), out, prompts, G, 1e-6)
+    xi = x.double().view(prompts, G, G, 256).permute(0, 3, 1, 2)
+    y = F.conv_transpose2d(xi, wt.double(), cb.double(), stride=2)                      # [B, 64, 2G, 2G]
+    y = F.layer_norm(y.permute(0, 2, 3, 1), (64,), lw.double(), lb.double(), 1e-6)
+    ref = F.gelu(y).reshape(prompts * 4 * G * G, 64)
+    err = (out.double() - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) <= 5e-3                                # one bf16 rounding of the result
+
+
+@pytest.mark.parametrize("prompts,G2", [(3, 64), (2, 32), (1, 128)])
+def test_sam_upscale_masks_matches_torch(pkg, cuda, prompts, G2):
+    """ConvTranspose2d(64, 32, 2, 2) + GELU + the product with the four hypernetwork vectors as one kernel."""
+    u = _rand((prompts * G2 * G2, 64), 31, cuda).to(torch.bfloat16)
+    wt = (_rand((64, 32, 2, 2), 32, cuda) * 0.15).to(torch.bfloat16)
+    cb = _rand((32,), 33, cuda) * 0.2
+    hyper = _rand((prompts, 4, 32), 34, cuda)
+    masks = torch.full((prompts, 4, 2 * G2, 2 * G2), float("nan"), device=cuda)
+    pkg.ops.sam_upscale_masks(u, wt.float().permute(2, 3, 1, 0).reshape(128, 64).contiguous().to(torch.bfloat16), cb, hyper, masks, prompts, G2)
+    ui = u.double().view(prompts, G2, G2, 64).permute(0, 3, 1, 2)
+    up = F.gelu(F.conv_transpose2d(ui, wt.double(), cb.double(), stride=2))             # [B, 32, 2 G2, 2 G2]
+    ref = torch.einsum("bmc,bchw->bmhw", hyper.double(), up)
+    assert float((masks.double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())

@@ -411,3 +411,28 @@ def test_encoder_fused_attention_agrees_with_three_launch_form(pkg, arch):
         feats[fused] = pred.features.float().clone()
     e_fused, e_three = maxdiff(feats[True], ref), maxdiff(feats[False], ref)
     assert e_fused < 1.5 * e_three + 1e-3 * float(ref.abs().max()), (e_fused, e_three)
+
+
+def test_fused_upscaling_agrees_with_stagewise_form(pkg, monkeypatch):
+    """At the shipped decoder width in bf16 the upscaling runs as two fused kernels: same logits (to bf16 rounding of
+    the intermediate they share) and the same IoU predictions as the product-per-stage form, on the real token geometry."""
+    sa = pkg.segment_anything
+    sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["geom"], seed=3)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8)
+    pts = np.stack([rng.uniform(0, 400, 6), rng.uniform(0, 300, 6)], -1)[:, None, :]
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MARS_SAM_FUSED_UPSCALE", flag)
+        sam = sa.sam_model_registry["geom"](state_dict=sd, device="cuda", dtype=torch.bfloat16)
+        assert sam.mask_decoder.fused_up == (flag == "1")
+        pred = sa.SamPredictor(sam)
+        pred.set_image(img)
+        coords = torch.as_tensor(pred.transform.apply_coords(pts, img.shape[:2]), dtype=torch.float32, device="cuda")
+        masks, iou, low = pred.predict_torch(coords, torch.ones(6, 1, dtype=torch.int32, device="cuda"), multimask_output=True, return_logits=True)
+        res.append((masks.float().clone(), iou.float().clone(), low.float().clone()))
+    (m1, i1, l1), (m0, i0, l0) = res
+    assert torch.equal(i1, i0)
+    scale = float(l0.abs().max())
+    assert float((l1 - l0).abs().max()) <= 2e-3 * scale
+    assert float(((m1 > 0) != (m0 > 0)).float().mean()) < 1e-3
