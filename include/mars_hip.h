@@ -341,6 +341,23 @@ int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int6
  * x0, y0, x1, y1 of (> thr)} (int32 x 6; the box of an empty mask is 0,0,0,0). */
 int marship_mask_stats(const float* masks, int n, int H, int W, float thr, float off, int32_t* out,
                        void* stream);
+/* One axis of a composed resampling as a banded table: output o reads inputs lo[o] .. lo[o] + size[o] - 1 with weights
+ * w[o * kmax + k] (device pointers). */
+typedef struct MarsAxisTable { const int32_t* lo; const int32_t* size; const float* w; int32_t kmax; } MarsAxisTable;
+/* Sam.postprocess_masks (segment_anything/modeling/sam.py:134-162) fused with what the automatic mask generator does
+ * with its result (automatic_mask_generator.py:417-441, utils/amg.py:155-175): the image-size logits are evaluated from the
+ * low-resolution ones [.., L, L] a band of `band` output rows at a time (first along x with tx [W entries], then along y
+ * with ty [H entries], the order and sums of marship_resample_axis) and never stored.  Plane p of the input starts at
+ * low + (p / nm) * stride_b + (p % nm) * stride_c.  max_rows = the most source rows any band reads (the caller computes it
+ * from ty; max_rows * W floats must fit in 64 KB of LDS).
+ * marship_resample_mask_stats: stats[p] of marship_mask_stats for planes 0 .. n-1.
+ * marship_resample_threshold: out[i] f32 [H, W] = (logits of plane sel[i] (or i when sel is NULL) > thr) as 0 / 1. */
+int marship_resample_mask_stats(const float* low, int64_t stride_b, int64_t stride_c, int nm, int n, int L, int H, int W,
+                                const MarsAxisTable* tx, const MarsAxisTable* ty, int band, int max_rows, float thr,
+                                float off, int32_t* stats, void* stream);
+int marship_resample_threshold(const float* low, int64_t stride_b, int64_t stride_c, int nm, const int32_t* sel, int nsel,
+                               int L, int H, int W, const MarsAxisTable* tx, const MarsAxisTable* ty, int band,
+                               int max_rows, float thr, float* out, void* stream);
 /* Dense embedding of mask prompts (segment_anything/modeling/prompt_encoder.py:51-58, 102-105): masks f32
  * [B, 1, 4G, 4G] -> out f32 [B, G*G, C] (token-major).  w1 [m4,1,2,2], w2 [m,m4,2,2], w3 [C,m] with their biases,
  * g / h = LayerNorm2d weight / bias. */

@@ -413,7 +413,128 @@ __global__ __launch_bounds__(256) void threshold_masks_kernel(const float* __res
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i] > thr ? 1.f : 0.f;
 }
 
+// Sam.postprocess_masks (two bilinear passes and a crop, composed into one banded table an axis) evaluated on the fly
+// from the low-resolution logits, a band of output rows at a time: the source rows the band needs are resampled along x
+// into LDS, then along y out of LDS - the two sums of resample_axis_kernel in the same order, so the values are the
+// ones the two-pass form writes - and consumed in place: by the mask statistics (STATS: a workgroup walks all bands of
+// one plane) or by the threshold (a workgroup owns one band of one selected plane and writes 0 / 1).  The image-size
+// logits never exist in memory.
+struct AxisTable { const int32_t* lo; const int32_t* size; const float* w; int kmax; };
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void resample_bands_kernel(const float* __restrict__ low, int64_t stride_b, int64_t stride_c, int nm,
+                                                             const int32_t* __restrict__ sel, int L, int H, int W, AxisTable tx, AxisTable ty,
+                                                             int band, int max_rows, float thr, float off, int32_t* __restrict__ stats,
+                                                             float* __restrict__ out) {
+    extern __shared__ float tmp[];                       // [max_rows][W]
+    __shared__ int sr[2];
+    __shared__ int sh[6][4];
+    const int slot = STATS ? blockIdx.x : blockIdx.y;
+    const int plane = (!STATS && sel) ? sel[slot] : slot;
+    const float* src = low + (int64_t)(plane / nm) * stride_b + (int64_t)(plane % nm) * stride_c;
+    int hi = 0, lo = 0, x0 = W, y0 = H, x1 = -1, y1 = -1;
+    const int nb = (H + band - 1) / band;
+    for (int b = STATS ? 0 : blockIdx.x; b < (STATS ? nb : blockIdx.x + 1); ++b) {
+        const int ya = b * band, yb = min(H, ya + band);
+        __syncthreads();                                  // (the previous band is done with tmp and sr)
+        if (threadIdx.x < 64) {                           // source rows [r0, r1) of this band
+            int r0 = L, r1 = 0;
+            for (int y = ya + (int)threadIdx.x; y < yb; y += 64) {
+                r0 = min(r0, ty.lo[y]);
+                r1 = max(r1, ty.lo[y] + ty.size[y]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                r0 = min(r0, __shfl_xor(r0, o, 64));
+                r1 = max(r1, __shfl_xor(r1, o, 64));
+            }
+            if (threadIdx.x == 0) { sr[0] = r0; sr[1] = min(min(r1, L), r0 + max_rows); }
+        }
+        __syncthreads();
+        const int r0 = sr[0], nr = max(sr[1] - r0, 0);
+        for (int x = threadIdx.x; x < W; x += 256) {
+            const int m0 = tx.lo[x], ms = tx.size[x];
+            const float* w = tx.w + (int64_t)x * tx.kmax;
+            for (int r = 0; r < nr; ++r) {
+                const float* sp = src + (int64_t)(r0 + r) * L + m0;
+                float acc = 0.f;
+                for (int k = 0; k < ms; ++k) acc = k == 0 ? sp[0] * w[0] : acc + sp[k] * w[k];
+                tmp[r * W + x] = acc;
+            }
+        }
+        __syncthreads();
+        for (int y = ya; y < yb; ++y) {
+            const int m0 = ty.lo[y] - r0, ms = min(ty.size[y], nr - m0);
+            const float* w = ty.w + (int64_t)y * ty.kmax;
+            for (int x = threadIdx.x; x < W; x += 256) {
+                float acc = 0.f;
+                for (int k = 0; k < ms; ++k) acc = k == 0 ? tmp[m0 * W + x] * w[0] : acc + tmp[(m0 + k) * W + x] * w[k];
+                if (STATS) {
+                    hi += acc > thr + off;
+                    lo += acc > thr - off;
+                    if (acc > thr) { x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y); }
+                } else {
+                    out[((int64_t)slot * H + y) * W + x] = acc > thr ? 1.f : 0.f;
+                }
+            }
+        }
+    }
+    if (!STATS) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64);
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wave] = hi; sh[1][wave] = lo; sh[2][wave] = x0; sh[3][wave] = y0; sh[4][wave] = x1; sh[5][wave] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t* o = stats + (int64_t)plane * 6;
+        o[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        o[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        const int bx0 = min(min(sh[2][0], sh[2][1]), min(sh[2][2], sh[2][3])), by0 = min(min(sh[3][0], sh[3][1]), min(sh[3][2], sh[3][3]));
+        const int bx1 = max(max(sh[4][0], sh[4][1]), max(sh[4][2], sh[4][3])), by1 = max(max(sh[5][0], sh[5][1]), max(sh[5][2], sh[5][3]));
+        const bool empty = bx1 < bx0 || by1 < by0;      // an empty mask has the box [0, 0, 0, 0]
+        o[2] = empty ? 0 : bx0; o[3] = empty ? 0 : by0; o[4] = empty ? 0 : bx1; o[5] = empty ? 0 : by1;
+    }
+}
+
+int check_bands(const char* what, const float* low, int nm, int L, int H, int W, const MarsAxisTable* tx, const MarsAxisTable* ty, int band,
+                int max_rows) {
+    MARS_CHECK(low && tx && ty && tx->lo && tx->size && tx->w && ty->lo && ty->size && ty->w, "%s: null pointer", what);
+    MARS_CHECK(nm > 0 && L > 0 && H > 0 && W > 0 && tx->kmax > 0 && ty->kmax > 0, "%s: bad shape", what);
+    MARS_CHECK(band > 0 && max_rows > 0 && max_rows <= L, "%s: band %d / rows %d", what, band, max_rows);
+    MARS_CHECK((size_t)max_rows * W * sizeof(float) <= 64 * 1024, "%s: %d source rows of %d samples do not fit in LDS; use a smaller band", what, max_rows, W);
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int marship_resample_mask_stats(const float* low, int64_t stride_b, int64_t stride_c, int nm, int n, int L, int H, int W,
+                                           const MarsAxisTable* tx, const MarsAxisTable* ty, int band, int max_rows, float thr, float off,
+                                           int32_t* stats, void* stream) {
+    if (check_bands("resample_mask_stats", low, nm, L, H, W, tx, ty, band, max_rows)) return -1;
+    MARS_CHECK(stats && n > 0, "resample_mask_stats: bad arguments");
+    const AxisTable ax = {tx->lo, tx->size, tx->w, tx->kmax}, ay = {ty->lo, ty->size, ty->w, ty->kmax};
+    hipLaunchKernelGGL(resample_bands_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)max_rows * W * sizeof(float), (hipStream_t)stream, low,
+                       stride_b, stride_c, nm, (const int32_t*)nullptr, L, H, W, ax, ay, band, max_rows, thr, off, stats, (float*)nullptr);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int marship_resample_threshold(const float* low, int64_t stride_b, int64_t stride_c, int nm, const int32_t* sel, int nsel, int L,
+                                          int H, int W, const MarsAxisTable* tx, const MarsAxisTable* ty, int band, int max_rows, float thr,
+                                          float* out, void* stream) {
+    if (check_bands("resample_threshold", low, nm, L, H, W, tx, ty, band, max_rows)) return -1;
+    MARS_CHECK(out && nsel > 0 && nsel <= 65535, "resample_threshold: %d planes (1 .. 65535 a launch)", nsel);
+    const AxisTable ax = {tx->lo, tx->size, tx->w, tx->kmax}, ay = {ty->lo, ty->size, ty->w, ty->kmax};
+    hipLaunchKernelGGL(resample_bands_kernel<false>, dim3((unsigned)((H + band - 1) / band), (unsigned)nsel), dim3(256),
+                       (size_t)max_rows * W * sizeof(float), (hipStream_t)stream, low, stride_b, stride_c, nm, sel, L, H, W, ax, ay, band, max_rows, thr,
+                       0.f, (int32_t*)nullptr, out);
+    MARS_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int marship_gather_rows(const void* src, int64_t ld_src, int src_col, const int32_t* idx, void* dst, int64_t ld_dst,
                                    int dst_col, int64_t rows, int ncols, int dtype, void* stream) {

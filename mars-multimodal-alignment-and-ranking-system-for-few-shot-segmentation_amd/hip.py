@@ -18,6 +18,10 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 
 
+class MarsAxisTable(Structure):
+    _fields_ = [("lo", c_void_p), ("size", c_void_p), ("w", c_void_p), ("kmax", c_int32)]
+
+
 class MarsGemm(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
@@ -89,6 +93,8 @@ _SIGNATURES = {
     "marship_sam_upscale_masks": [_P, _L, _P, _P, _P, _L, _P, _L, _I, _P],
     "marship_hyper_product": [_P, _L, _P, _L, _P, _I, _L, _I, _P],
     "marship_mask_embed": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P],
+    "marship_resample_mask_stats": [_P, _L, _L, _I, _I, _I, _I, _I, POINTER(MarsAxisTable), POINTER(MarsAxisTable), _I, _I, _F, _F, _P, _P],
+    "marship_resample_threshold": [_P, _L, _L, _I, _P, _I, _I, _I, _I, POINTER(MarsAxisTable), POINTER(MarsAxisTable), _I, _I, _F, _P, _P],
     "marship_mask_stats": [_P, _I, _I, _I, _F, _F, _P, _P],
     "marship_threshold_masks": [_P, _F, _P, _L, _P],
     "marshost_box_nms": [_P, _P, _I, _F, _P, _P],

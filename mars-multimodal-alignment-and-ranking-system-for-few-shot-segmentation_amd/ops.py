@@ -775,6 +775,55 @@ def mask_stats(masks: torch.Tensor, thr: float, off: float, out: torch.Tensor):
     hip.check(hip.lib().marship_mask_stats(ptr(masks), n, H, W, float(thr), float(off), ptr(out), stream()), "marship_mask_stats")
 
 
+def _axis_table(t) -> "hip.MarsAxisTable":
+    lo, size, w = t
+    _dev(lo, size, w)
+    _req(lo.dtype == torch.int32 and size.dtype == torch.int32 and w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+         and lo.numel() == w.shape[0] and size.numel() == w.shape[0], "axis table = (lo i32 [n], size i32 [n], weights f32 [n, kmax])")
+    a = hip.MarsAxisTable()
+    a.lo, a.size, a.w, a.kmax = lo.data_ptr(), size.data_ptr(), w.data_ptr(), w.shape[1]
+    return a
+
+
+def _low_planes(low: torch.Tensor):
+    _req(low.dim() == 4 and low.dtype == torch.float32 and low.shape[2] == low.shape[3] and low.stride(3) == 1 and low.stride(2) == low.shape[3],
+         "low-resolution logits must be f32 [B, nm, L, L] with contiguous planes")
+    B, nm, L, _ = low.shape
+    _req((B - 1) * low.stride(0) + (nm - 1) * low.stride(1) + L * L <= _avail(low), "low-resolution logits overrun their buffer")
+    return B, nm, L
+
+
+def resample_mask_stats(low: torch.Tensor, tx, ty, band: int, max_rows: int, thr: float, off: float, out: torch.Tensor):
+    """mask_stats of the image-size logits that (tx, ty) make from ``low`` [B, nm, L, L] (a view is fine), without storing them:
+    out i32 [B*nm, 6].  (band, max_rows) from resample.band_plan on the host copy of ty."""
+    B, nm, L = _low_planes(low)
+    _dev(low, out)
+    _req(out.dtype == torch.int32 and out.is_contiguous() and out.numel() >= 6 * B * nm, "resample_mask_stats: out")
+    ax, ay = _axis_table(tx), _axis_table(ty)
+    hip.check(hip.lib().marship_resample_mask_stats(ptr(low), low.stride(0), low.stride(1), nm, B * nm, L, ty[0].numel(), tx[0].numel(),
+                                                    ctypes.byref(ax), ctypes.byref(ay), band, max_rows, float(thr), float(off), ptr(out), stream()),
+              "marship_resample_mask_stats")
+
+
+def resample_threshold(low: torch.Tensor, sel: Optional[torch.Tensor], tx, ty, band: int, max_rows: int, thr: float, out: torch.Tensor):
+    """out[i] f32 [H, W] = 0 / 1 of (image-size logits of plane sel[i] of ``low`` [B, nm, L, L] > thr); sel i32 on the device
+    (None: every plane in order)."""
+    B, nm, L = _low_planes(low)
+    _dev(low, out, sel)
+    H, W = ty[0].numel(), tx[0].numel()
+    n = B * nm if sel is None else sel.numel()
+    _req(sel is None or (sel.dtype == torch.int32 and sel.is_contiguous()), "resample_threshold: sel must be i32")
+    _req(out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n * H * W, "resample_threshold: out")
+    ax, ay = _axis_table(tx), _axis_table(ty)
+    for a in range(0, n, 65535):                                      # (grid limit a launch)
+        k = min(65535, n - a)
+        if sel is None:
+            _req(n <= 65535, "resample_threshold: more than 65535 planes need a selection")
+        hip.check(hip.lib().marship_resample_threshold(ptr(low), low.stride(0), low.stride(1), nm, (sel.data_ptr() + 4 * a) if sel is not None else None, k,
+                                                       L, H, W, ctypes.byref(ax), ctypes.byref(ay), band, max_rows, float(thr),
+                                                       out.data_ptr() + 4 * a * H * W, stream()), "marship_resample_threshold")
+
+
 def threshold_masks(src: torch.Tensor, thr: float, dst: torch.Tensor):
     _dev(src, dst)
     _req(src.dtype == torch.float32 and dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() >= src.numel(),

@@ -159,3 +159,19 @@ def sam_postprocess_table(low_size: int, img_size: int, input_len: int, orig_len
     into a single banded table."""
     up = torch_bilinear_matrix(low_size, img_size)[:input_len]
     return matrix_to_table(torch_bilinear_matrix(input_len, orig_len) @ up)
+
+
+def band_plan(table_y, in_rows: int, width: int, lds_bytes: int = 64 * 1024, bands=(16, 8, 4, 2, 1)):
+    """For the banded evaluation of a two-axis resampling (x into LDS, then y out of LDS): the largest band of output rows
+    whose source rows (of ``width`` f32 samples each) fit in ``lds_bytes``.  table_y = (lo, size, weights) of the y axis on
+    the host.  Returns (band, max_rows) or None."""
+    lo, size = np.asarray(table_y[0], np.int64), np.asarray(table_y[1], np.int64)
+    if lo.size == 0 or int((lo + size).max()) > in_rows or int(lo.min()) < 0:
+        return None
+    for band in bands:
+        rows = 1
+        for a in range(0, lo.size, band):
+            rows = max(rows, int((lo[a:a + band] + size[a:a + band]).max() - lo[a:a + band].min()))
+        if rows * width * 4 <= lds_bytes:
+            return band, rows
+    return None

@@ -67,24 +67,39 @@ class SamAutomaticMaskGenerator:
     # ------------------------------------------------------------------ lines 385-453 and 455-556
     def _pick_layers(self, layer: int, masks, iou, low):
         """Output selection shared by both prompt paths (lines 405-415, 508-518; both test sel_multimask_output)."""
+        cut = lambda t, sl: None if t is None else t[:, sl]
         if self.sel_multimask_output:
             if layer in (0, 1, 2):
-                return masks[:, layer:layer + 1], iou[:, layer:layer + 1], low[:, layer:layer + 1]
+                return cut(masks, slice(layer, layer + 1)), iou[:, layer:layer + 1], low[:, layer:layer + 1]
             if layer in (3, 4, 5):
-                return masks[:, layer - 3:], iou[:, layer - 3:], low[:, layer - 3:]
+                return cut(masks, slice(layer - 3, None)), iou[:, layer - 3:], low[:, layer - 3:]
         return masks, iou, low
 
+    def _fused_post(self) -> bool:
+        """Whether the image-size logits are evaluated on the fly inside the statistics and threshold kernels (no
+        [B, C, H, W] tensor); MARS_SAM_FUSED_POST=0 keeps postprocess_masks + mask_stats + threshold_masks."""
+        pr = self.predictor
+        L = 4 * pr.model.prompt_encoder.image_embedding_size[0]
+        return os.environ.get("MARS_SAM_FUSED_POST", "1") != "0" and pr.model.postprocess_plan(L, pr.input_size, pr.original_size) is not None
+
     def _keep_batch(self, masks, iou, low, points: list, iou_thresh: float, stab_thresh: float, stab_off: float, keep_lists: dict):
-        """masks [B, C, H, W] logits: one statistics launch, the two filters on the host, survivors kept as
-        {0,1} floats on the GPU.  ``points`` holds the prompt points of every batch row."""
+        """masks [B, C, H, W] logits (or None: they are evaluated from ``low`` [B, C, L, L] on the fly): one statistics
+        launch, the two filters on the host, survivors kept as {0,1} floats on the GPU.  ``points`` holds the prompt
+        points of every batch row."""
         pr, dev = self.predictor, self.predictor.device
-        nm = masks.shape[1]
-        masks, iou, low = masks.flatten(0, 1).contiguous(), iou.flatten(0, 1), low.flatten(0, 1)
-        stats = torch.empty(masks.shape[0], 6, dtype=torch.int32, device=dev)
-        ops.mask_stats(masks, pr.model.mask_threshold, stab_off, stats)
+        nm, n = low.shape[1], low.shape[0] * low.shape[1]
+        iou = iou.flatten(0, 1)
+        stats = torch.empty(n, 6, dtype=torch.int32, device=dev)
+        plan = None
+        if masks is None:                                             # logits evaluated from ``low`` inside the kernels
+            plan = pr.model.postprocess_plan(low.shape[-1], pr.input_size, pr.original_size)
+            ops.resample_mask_stats(low, *plan, pr.model.mask_threshold, stab_off, stats)
+        else:
+            masks = masks.flatten(0, 1).contiguous()
+            ops.mask_stats(masks, pr.model.mask_threshold, stab_off, stats)
         st, iou_h = stats.cpu(), iou.cpu()
         stab = st[:, 0].float() / st[:, 1].float()                    # intersections / unions (amg.py:173)
-        keep = torch.ones(masks.shape[0], dtype=torch.bool)
+        keep = torch.ones(n, dtype=torch.bool)
         if iou_thresh > 0.0:
             keep &= iou_h > iou_thresh
         if stab_thresh > 0.0:
@@ -93,21 +108,29 @@ class SamAutomaticMaskGenerator:
         if idx.numel() == 0:
             return
         sel = idx.to(dev)
-        kept = masks[sel].contiguous()
-        binm = torch.empty_like(kept)
-        ops.threshold_masks(kept, pr.model.mask_threshold, binm)
+        if masks is None:
+            oh, ow = pr.original_size
+            binm = torch.empty(idx.numel(), int(oh), int(ow), dtype=torch.float32, device=dev)
+            ops.resample_threshold(low, idx.to(torch.int32).to(dev), *plan, pr.model.mask_threshold, binm)
+            low_kept = low[sel // nm, sel % nm]
+        else:
+            kept = masks[sel].contiguous()
+            binm = torch.empty_like(kept)
+            ops.threshold_masks(kept, pr.model.mask_threshold, binm)
+            low_kept = low.flatten(0, 1)[sel]
         keep_lists["masks"].append(binm)
         keep_lists["iou"].append(iou_h[idx])
         keep_lists["stab"].append(stab[idx])
         keep_lists["boxes"].append(st[idx, 2:6].float())
         keep_lists["points"].extend(points[int(i) // nm] for i in idx.tolist())      # rows repeat once per output mask
-        keep_lists["low"].append(low[sel])
+        keep_lists["low"].append(low_kept)
 
     def _process_batch(self, points: np.ndarray, im_size, keep_lists: dict):
         pr, dev = self.predictor, self.predictor.device
         tp = torch.as_tensor(pr.transform.apply_coords(points, im_size), dtype=torch.float32, device=dev)
         labels = torch.ones(tp.shape[0], 1, dtype=torch.int32, device=dev)
-        masks, iou, low = pr.predict_torch(tp[:, None, :], labels, multimask_output=self.multimask_output, return_logits=True)
+        masks, iou, low = pr.predict_torch(tp[:, None, :], labels, multimask_output=self.multimask_output, return_logits=True,
+                                           upscale=not self._fused_post())
         masks, iou, low = self._pick_layers(self.output_layer, masks, iou, low)
         self._keep_batch(masks, iou, low, [[p] for p in points.tolist()], self.pred_iou_thresh, self.stability_score_thresh,
                          self.stability_score_offset, keep_lists)
@@ -130,7 +153,7 @@ class SamAutomaticMaskGenerator:
             mask_input = torch.as_tensor(np.asarray(mask_input), dtype=torch.float32, device=dev)
             mask_input = mask_input[None] if mask_input.dim() == 3 else mask_input
         masks, iou, low = pr.predict_torch(tp, labels, boxes=boxes, mask_input=mask_input, multimask_output=self.sel_multimask_output,
-                                           return_logits=True)
+                                           return_logits=True, upscale=not self._fused_post())
         masks, iou, low = self._pick_layers(self.sel_output_layer, masks, iou, low)
         self._keep_batch(masks, iou, low, point_coords.tolist(), self.sel_pred_iou_thresh, self.sel_stability_score_thresh,
                          self.sel_stability_score_offset, keep_lists)

@@ -628,6 +628,18 @@ class Sam:
             t = self._tables[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(self.device) for a in fn(*args))
         return t
 
+    def postprocess_plan(self, L: int, input_size: Tuple[int, int], original_size: Tuple[int, int]):
+        """The tables of postprocess_masks together with the band plan of the kernels that evaluate it on the fly
+        (ops.resample_mask_stats / resample_threshold): (tx, ty, band, max_rows), or None when no band fits in LDS."""
+        S = self.cfg.img_size
+        oh, ow = int(original_size[0]), int(original_size[1])
+        key = ("plan", L, S, int(input_size[0]), int(input_size[1]), oh, ow)
+        if key not in self._tables:
+            bp = resample.band_plan(resample.sam_postprocess_table(L, S, int(input_size[0]), oh), L, ow)
+            self._tables[key] = None if bp is None else (self._table("post", L, S, int(input_size[1]), ow),
+                                                         self._table("post", L, S, int(input_size[0]), oh), bp[0], bp[1])
+        return self._tables[key]
+
     def postprocess_masks(self, masks: torch.Tensor, input_size: Tuple[int, int], original_size: Tuple[int, int]) -> torch.Tensor:
         """sam.py:134-162: [B, C, 4G, 4G] logits -> [B, C, H, W] logits (both bilinear passes and the crop
         in one table per axis)."""

@@ -79,9 +79,10 @@ class SamPredictor:
         self.is_image_set = True
 
     def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output: bool = True,
-                      return_logits: bool = False):
+                      return_logits: bool = False, upscale: bool = True):
         """predictor.py:177-251: coords [B, N, 2] and boxes [B, 4] in the model's input frame, labels [B, N],
-        mask_input [B or 1, 1, 4G, 4G] low-resolution logits of an earlier prediction."""
+        mask_input [B or 1, 1, 4G, 4G] low-resolution logits of an earlier prediction.  ``upscale=False`` (not in the reference)
+        skips postprocess_masks and returns (None, iou, low)."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
         m = self.model
@@ -93,6 +94,8 @@ class SamPredictor:
         masks4, iou4 = m.mask_decoder.predict_masks(self.features_tokens, m.prompt_encoder.dense_pe_tokens, sparse,
                                                     m.prompt_encoder.no_mask, dense_tokens=dense_tokens)
         sl = slice(1, None) if multimask_output else slice(0, 1)
+        if not upscale:             # (for callers that evaluate the image-size logits on the fly: a view of the decoder's buffer,
+            return None, iou4[:, sl].contiguous(), masks4[:, sl]        #  valid until the next prediction)
         low, iou = masks4[:, sl].contiguous(), iou4[:, sl].contiguous()
         masks = m.postprocess_masks(low, self.input_size, self.original_size)
         if not return_logits:

@@ -10,6 +10,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package  # noqa: E402
@@ -436,3 +437,62 @@ def test_fused_upscaling_agrees_with_stagewise_form(pkg, monkeypatch):
     scale = float(l0.abs().max())
     assert float((l1 - l0).abs().max()) <= 2e-3 * scale
     assert float(((m1 > 0) != (m0 > 0)).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("L,S,inp,orig", [(256, 1024, (768, 1024), (480, 640)), (32, 128, (128, 96), (333, 250)), (64, 256, (171, 256), (100, 150)),
+                                           (256, 1024, (1024, 683), (1500, 1000))])
+def test_on_the_fly_postprocess_equals_the_stored_form(pkg, L, S, inp, orig):
+    """Statistics and 0 / 1 masks evaluated from the low-resolution logits inside the kernels == postprocess_masks
+    (two stored passes) followed by mask_stats / threshold_masks, bit for bit; a strided view of four planes a prompt."""
+    ops, rs = pkg.ops, pkg.resample
+    dev = torch.device("cuda")
+    oh, ow = orig
+    th_h, tw_h = rs.sam_postprocess_table(L, S, inp[0], oh), rs.sam_postprocess_table(L, S, inp[1], ow)
+    up = lambda t: tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in t)
+    th, tw = up(th_h), up(tw_h)
+    band, rows = rs.band_plan(th_h, L, ow)
+    B, nm = 5, 3
+    g = torch.Generator().manual_seed(L + oh)
+    base = (torch.randn(B, 4, L // 8, L // 8, generator=g) * 6).to(dev)
+    low4 = F.interpolate(base, size=(L, L), mode="bilinear") + torch.randn(B, 4, L, L, generator=g).to(dev) * 0.3
+    low4[1, 2] = -5.0                                                      # an empty mask
+    low = low4[:, 1:]                                                      # a view: planes 1..3 of every prompt
+    tmp = torch.empty(B * nm, L, ow, device=dev); full = torch.empty(B * nm, oh, ow, device=dev)
+    lc = low.contiguous()
+    ops.resample_axis(lc, B * nm, L, L, 1, tw, tmp)
+    ops.resample_axis(tmp, B * nm, L, ow, 0, th, full)
+    want = torch.empty(B * nm, 6, dtype=torch.int32, device=dev)
+    ops.mask_stats(full, 0.0, 1.0, want)
+    got = torch.full_like(want, -7)
+    ops.resample_mask_stats(low, tw, th, band, rows, 0.0, 1.0, got)
+    assert torch.equal(got, want)
+    assert int(want[4, 0]) == 0 and want[4, 2:].tolist() == [0, 0, 0, 0]   # (plane 4 = prompt 1, mask 2 of the view)
+    sel = torch.tensor([7, 0, 14, 4, 3], dtype=torch.int32, device=dev)
+    bits = torch.full((5, oh, ow), 9.0, device=dev)
+    ops.resample_threshold(low, sel, tw, th, band, rows, 0.0, bits)
+    assert torch.equal(bits, (full[sel.long()] > 0.0).float())
+    allb = torch.empty(B * nm, oh, ow, device=dev)
+    ops.resample_threshold(low, None, tw, th, band, rows, 0.0, allb)
+    assert torch.equal(allb, (full > 0.0).float())
+
+
+def test_generator_on_the_fly_postprocess_gives_the_same_records(pkg, monkeypatch):
+    sa = pkg.segment_anything
+    sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["tiny"], seed=5)
+    img = GOLD["sam_tiny_image"]
+    recs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MARS_SAM_FUSED_POST", flag)
+        sam = sa.sam_model_registry["tiny"](state_dict=sd, device="cuda")
+        amg = sa.SamAutomaticMaskGenerator(sam, points_per_side=6, points_per_batch=7, pred_iou_thresh=-10.0, stability_score_thresh=0.02)
+        calls = []
+        orig = pkg.ops.resample_mask_stats
+        monkeypatch.setattr(pkg.ops, "resample_mask_stats", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        recs.append(amg.generate(img))
+        monkeypatch.setattr(pkg.ops, "resample_mask_stats", orig)
+        assert bool(calls) == (flag == "1")
+    a, b = recs
+    assert len(a) == len(b) and len(a) > 0
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["segmentation"], rb["segmentation"]) and ra["bbox"] == rb["bbox"] and ra["area"] == rb["area"]
+        assert ra["predicted_iou"] == rb["predicted_iou"] and ra["stability_score"] == rb["stability_score"]
