@@ -8,10 +8,12 @@
 //               prompt sit in LDS as f32; scores, softmax and P V stay in registers.  The eight heads of a row are
 //               eight neighbouring lanes, so a wave reads and writes whole rows.
 //   few queries (Tq <= 8 a pass; tokens -> image): a workgroup owns one prompt; a thread owns (key lane, head) and
-//               walks the keys with an online softmax state per query in registers (queries in LDS); the key lanes
+//               walks the keys (the next key's rows in flight while the current one is used) with an online softmax
+//               state per query in registers (queries in LDS); the key lanes
 //               that share a head are combined by shuffles and one pass through LDS.
 //
-// f32 accumulation and f32 exponentials (expf) in both, operands and results f32 or bf16.
+// f32 accumulation and f32 exponentials in both (expf for few keys; few queries keeps its scores in units of log 2 and
+// uses v_exp_f32), operands and results f32 or bf16.
 #include "common.h"
 #include "../../include/mars_hip.h"
 
@@ -52,8 +54,8 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, const float (&x)[HD
     }
 }
 
-// few keys: grid (ceil(Tq / (256 / H)), B); LDS: K then V of the prompt as f32 [Tk][H * HD]
-template <typename T, int HD, int TKMAX>
+// few keys: grid (ceil(Tq / (ROWS_IT * 256 / H)), B); LDS: K then V of the prompt as f32 [Tk][H * HD]
+template <typename T, int HD, int TKMAX, int ROWS_IT>
 __global__ __launch_bounds__(256) void attn_few_keys_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk,
                                                             const T* __restrict__ v, int64_t ldv, T* __restrict__ out, int64_t ldo, int H,
                                                             int Tq, int Tk, float scale, int qb, int kb) {
@@ -67,44 +69,48 @@ __global__ __launch_bounds__(256) void attn_few_keys_kernel(const T* __restrict_
         sV[i] = (float)v[((int64_t)b * kb + j) * ldv + c];
     }
     __syncthreads();
-    const int row = blockIdx.x * (256 / H) + tid / H, h = tid % H;
-    if (row >= Tq || tid >= (256 / H) * H) return;
-    float qv[HD];
-    load_row<T, HD>(q + ((int64_t)b * qb + row) * ldq + h * HD, qv);
-    float s[TKMAX];
-    float m = -INFINITY;
+    const int h = tid % H;
+    // ROWS_IT passes of 256 / H rows a workgroup: the LDS copy above is paid once for all of them
+    for (int it = 0; it < ROWS_IT; ++it) {
+        const int row = (blockIdx.x * ROWS_IT + it) * (256 / H) + tid / H;
+        if (row >= Tq) return;
+        float qv[HD];
+        load_row<T, HD>(q + ((int64_t)b * qb + row) * ldq + h * HD, qv);
+        float s[TKMAX];
+        float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < TKMAX; ++j) {
-        s[j] = -INFINITY;
-        if (j < Tk) {
-            const float* kr = sK + j * W + h * HD;
-            float d = 0.f;
+        for (int j = 0; j < TKMAX; ++j) {
+            s[j] = -INFINITY;
+            if (j < Tk) {
+                const float* kr = sK + j * W + h * HD;
+                float d = 0.f;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) d = fmaf(qv[e], kr[e], d);
-            s[j] = d * scale;
-            m = fmaxf(m, s[j]);
+                for (int e = 0; e < HD; ++e) d = fmaf(qv[e], kr[e], d);
+                s[j] = d * scale;
+                m = fmaxf(m, s[j]);
+            }
         }
-    }
-    float l = 0.f;
+        float l = 0.f;
 #pragma unroll
-    for (int j = 0; j < TKMAX; ++j) {
-        s[j] = j < Tk ? expf(s[j] - m) : 0.f;
-        l += s[j];
-    }
-    float o[HD];
-#pragma unroll
-    for (int e = 0; e < HD; ++e) o[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < TKMAX; ++j)
-        if (j < Tk) {
-            const float* vr = sV + j * W + h * HD;
-#pragma unroll
-            for (int e = 0; e < HD; ++e) o[e] = fmaf(s[j], vr[e], o[e]);
+        for (int j = 0; j < TKMAX; ++j) {
+            s[j] = j < Tk ? expf(s[j] - m) : 0.f;
+            l += s[j];
         }
-    const float inv = 1.0f / l;
+        float o[HD];
 #pragma unroll
-    for (int e = 0; e < HD; ++e) o[e] *= inv;
-    store_row<T, HD>(out + ((int64_t)b * Tq + row) * ldo + h * HD, o);
+        for (int e = 0; e < HD; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TKMAX; ++j)
+            if (j < Tk) {
+                const float* vr = sV + j * W + h * HD;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) o[e] = fmaf(s[j], vr[e], o[e]);
+            }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) o[e] *= inv;
+        store_row<T, HD>(out + ((int64_t)b * Tq + row) * ldo + h * HD, o);
+    }
 }
 
 // few queries: grid (B); queries q0 .. q0 + nq - 1 (nq <= TQ) of every prompt.  LDS: the queries as f32 [TQ][H * HD],
@@ -117,9 +123,10 @@ __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restri
     const int W = H * HD, b = blockIdx.x, tid = threadIdx.x;
     float* sQ = sm;                                   // [TQ][W]
     float* sP = sm + TQ * W;                          // [4][H][TQ][HD + 2]
+    // scores are kept in units of log 2 (the scale carries log2 e), so every exponential is one v_exp_f32
     for (int i = tid; i < nq * W; i += 256) {
         const int j = i / W, c = i - j * W;
-        sQ[i] = (float)q[((int64_t)b * qb + q0 + j) * ldq + c] * scale;
+        sQ[i] = (float)q[((int64_t)b * qb + q0 + j) * ldq + c] * (scale * 1.44269504088896340736f);
     }
     __syncthreads();
     const int h = tid % H, kl = tid / H, nkl = 256 / H;          // key lanes: keys kl, kl + nkl, ...
@@ -131,10 +138,22 @@ __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restri
 #pragma unroll
         for (int e = 0; e < HD; ++e) acc[j][e] = 0.f;
     }
+    // the rows of the next key are requested before the current one is used
+    typedef T raw_t __attribute__((ext_vector_type(HD)));
+    const T* kp = k + ((int64_t)b * kb + kl) * ldk + h * HD;
+    const T* vp = v + ((int64_t)b * kb + kl) * ldv + h * HD;
+    raw_t kr = {}, vr = {};
+    if (kl < Tk) { kr = *(const raw_t*)kp; vr = *(const raw_t*)vp; }
     for (int key = kl; key < Tk; key += nkl) {
         float kv[HD], vv[HD];
-        load_row<T, HD>(k + ((int64_t)b * kb + key) * ldk + h * HD, kv);
-        load_row<T, HD>(v + ((int64_t)b * kb + key) * ldv + h * HD, vv);
+#pragma unroll
+        for (int e = 0; e < HD; ++e) { kv[e] = (float)kr[e]; vv[e] = (float)vr[e]; }
+        if (key + nkl < Tk) {
+            kp += (int64_t)nkl * ldk;
+            vp += (int64_t)nkl * ldv;
+            kr = *(const raw_t*)kp;
+            vr = *(const raw_t*)vp;
+        }
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
             if (j < nq) {
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restri
 #pragma unroll
                 for (int e = 0; e < HD; ++e) s = fmaf(qr[e], kv[e], s);
                 const float mn = fmaxf(m[j], s);
-                const float a = expf(m[j] - mn), p = expf(s - mn);       // (m = -inf at the first key: a = 0)
+                const float a = __builtin_amdgcn_exp2f(m[j] - mn), p = __builtin_amdgcn_exp2f(s - mn);       // (m = -inf at the first key: a = 0)
                 l[j] = l[j] * a + p;
 #pragma unroll
                 for (int e = 0; e < HD; ++e) acc[j][e] = fmaf(acc[j][e], a, p * vv[e]);
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restri
             for (int off = H; off < 64; off <<= 1) {
                 const float mo = __shfl_xor(m[j], off), lo = __shfl_xor(l[j], off);
                 const float mn = fmaxf(m[j], mo);
-                const float a = m[j] == -INFINITY ? 0.f : expf(m[j] - mn), bsc = mo == -INFINITY ? 0.f : expf(mo - mn);
+                const float a = m[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m[j] - mn), bsc = mo == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mo - mn);
                 l[j] = l[j] * a + lo * bsc;
 #pragma unroll
                 for (int e = 0; e < HD; ++e) acc[j][e] = acc[j][e] * a + __shfl_xor(acc[j][e], off) * bsc;
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_few_queries_kernel(const T* __restri
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const float* src = sP + (((size_t)w * H + hh) * TQ + j) * (HD + 2);
-            const float a = src[0] == -INFINITY ? 0.f : expf(src[0] - mn);
+            const float a = src[0] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(src[0] - mn);
             lt += src[1] * a;
             at += src[2 + e] * a;
         }
@@ -198,11 +217,17 @@ int launch_small(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
                  int Tq, int Tk, float scale, int shared, hipStream_t s) {
     const int W = H * HD, qb = (shared & 1) ? 0 : Tq, kb = (shared & 2) ? 0 : Tk;
     if (Tk <= 16) {
-        const dim3 grid((unsigned)((Tq + 256 / H - 1) / (256 / H)), (unsigned)B), block(256);
-        if (Tk <= 8) hipLaunchKernelGGL((attn_few_keys_kernel<T, HD, 8>), grid, block, 2 * 8 * W * sizeof(float), s, (const T*)q, ldq, (const T*)k, ldk,
-                                        (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale, qb, kb);
-        else hipLaunchKernelGGL((attn_few_keys_kernel<T, HD, 16>), grid, block, 2 * 16 * W * sizeof(float), s, (const T*)q, ldq, (const T*)k, ldk,
-                                (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale, qb, kb);
+        const int rpp = 256 / H;                          // rows a pass
+        const dim3 block(256);
+#define MARS_FEW_KEYS(TKM, IT)                                                                                                                \
+    hipLaunchKernelGGL((attn_few_keys_kernel<T, HD, TKM, IT>), dim3((unsigned)((Tq + rpp * IT - 1) / (rpp * IT)), (unsigned)B), block,             \
+                       2 * TKM * W * sizeof(float), s, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, (T*)out, ldo, H, Tq, Tk, scale, qb, kb)
+        if (Tq >= 8 * rpp) {
+            if (Tk <= 8) MARS_FEW_KEYS(8, 8); else MARS_FEW_KEYS(16, 8);
+        } else {
+            if (Tk <= 8) MARS_FEW_KEYS(8, 1); else MARS_FEW_KEYS(16, 1);
+        }
+#undef MARS_FEW_KEYS
         MARS_LAUNCH_CHECK();
         return 0;
     }

@@ -184,7 +184,7 @@ class SamAutomaticMaskGenerator:
         if not lists["iou"]:
             return None
         points = lists.pop("points")
-        cat = {k: torch.cat(v, dim=0) for k, v in lists.items()}
+        cat = {k: (v[0] if len(v) == 1 else torch.cat(v, dim=0)) for k, v in lists.items()}      # (cat copies even a single tensor)
         ok = ~is_box_near_crop_edge(cat["boxes"], crop_box, [0, 0, ow, oh])           # lines 443-446
         order = ops.box_nms_host(cat["boxes"][ok], cat["iou"][ok], self.box_nms_thresh)
         keep = torch.nonzero(ok).flatten()[order]
@@ -213,7 +213,7 @@ class SamAutomaticMaskGenerator:
         if not parts:
             return dict(masks=torch.zeros(0, oh, ow, device=self.predictor.device), iou=torch.zeros(0), stab=torch.zeros(0),
                         boxes=torch.zeros(0, 4), points=[], low=None, crop_boxes=torch.zeros(0, 4), size=(oh, ow))
-        out = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0] if k != "points"}
+        out = {k: (parts[0][k] if len(parts) == 1 else torch.cat([p[k] for p in parts], dim=0)) for k in parts[0] if k != "points"}
         out["points"] = [pt for p in parts for pt in p["points"]]
         if len(boxes) > 1:                                                            # duplicates between crops: the smaller crop wins
             cb = out["crop_boxes"]
