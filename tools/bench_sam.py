@@ -57,7 +57,8 @@ def main():
         t0 = time.perf_counter()
         recs = amg.generate(img)
         torch.cuda.synchronize()
-        print(f"generate (32x32 points): {(time.perf_counter() - t0) * 1e3:.1f} ms, {len(recs)} records", flush=True)
+        print(f"generate (32x32 points), first call (buffers allocated, tables built): {(time.perf_counter() - t0) * 1e3:.1f} ms, {len(recs)} records", flush=True)
+        print(f"generate (32x32 points), warm: {timed(lambda: amg.generate(img), 2):.1f} ms", flush=True)
         q = torch.as_tensor(img).permute(2, 0, 1)[None].float().div(255).cuda()
         gen = sa.ProposalGenerator(amg, 100)
         print(f"proposals [100, H, W]: {timed(lambda: gen.generate(None, None, q), 2):.1f} ms", flush=True)
