@@ -370,6 +370,18 @@ class MaskDecoder:
                      n1=ln(p + ".norm1"), n2=ln(p + ".norm2"), n3=ln(p + ".norm3"), n4=ln(p + ".norm4"),
                      lin1=Lin(sd[p + ".mlp.lin1.weight"], sd[p + ".mlp.lin1.bias"], dtype, dev),
                      lin2=Lin(sd[p + ".mlp.lin2.weight"], sd[p + ".mlp.lin2.bias"], dtype, dev))
+            # image -> token attention, norm4 and the next layer's operands as one kernel (ops.sam_i2t_block) at the shipped
+            # width in bf16: Wq in runs of eight K, run-major; Wo the same with its K index in the order a lane holds o
+            A = L["i2t"]
+            if C == 256 and A.H == 8 and A.hd == 16 and dtype == torch.bfloat16 and os.environ.get("MARS_SAM_FUSED_I2T", "1") != "0":
+                pi = p + ".cross_attn_image_to_token"
+                wq, wo = sd[pi + ".q_proj.weight"].float(), sd[pi + ".out_proj.weight"].float()          # [128, 256], [256, 128]
+                slot = torch.tensor([16 * h + 8 * (e // 4) + 4 * g + e % 4 for h in range(8) for g in range(2) for e in range(8)])
+                L["i2t_fused"] = dict(
+                    wq=wq.view(128, 32, 8).permute(1, 0, 2).contiguous().to(dev, torch.bfloat16),
+                    wo=wo[:, slot].view(256, 16, 8).permute(1, 0, 2).contiguous().to(dev, torch.bfloat16),
+                    prm=torch.cat([sd[pi + ".q_proj.bias"].float(), sd[pi + ".out_proj.bias"].float(), sd[p + ".norm4.weight"].float(),
+                                   sd[p + ".norm4.bias"].float()]).contiguous().to(dev))
             self.layers.append(L)
         self.final = _DecAttn(sd, pre + ".final_attn_token_to_image", C, cfg.dec_heads, 2, dev, dtype)
         self.nf = ln(pre + ".norm_final_attn")
@@ -510,6 +522,18 @@ class MaskDecoder:
             # (4) the image attends to the tokens
             ops.add_cast(Q, pe2, qd)
             ops.add_cast(Q, None, td)
+            last = i + 1 == len(self.layers)
+            if "i2t_fused" in L and Nt <= 8 and Ni % 32 == 0:
+                A, Fz = L["i2t"], L["i2t_fused"]
+                k = self._buf("i2tks", (B * Nt, 128)); v = self._buf("i2tvs", (B * Nt, 128))
+                ops.linear(qd, A.ks.w, k, bias=A.ks.b)
+                ops.linear(td, A.vs.w, v, bias=A.vs.b)
+                kvo = self._buf("i2tkv", (B, 8, 64, 2, 8))
+                ops.sam_i2t_kv_operands(k, v, B, Nt, kvo)
+                first0 = share0 and i == 0
+                ops.sam_i2t_block(kd0 if first0 else kd, Fz["wq"], Fz["wo"], Fz["prm"], kvo, Nt, src0 if first0 else Kf, dense_pe_tokens, B, Ni,
+                                  1e-5, None if last else Kf, kd, vd)
+                continue
             if share0 and i == 0:
                 self._attention(L["i2t"], "i2t", kd0, qd, td, B, Ni, Nt, Kf, src0, q_shared=True)
             else:

@@ -496,3 +496,28 @@ def test_generator_on_the_fly_postprocess_gives_the_same_records(pkg, monkeypatc
     for ra, rb in zip(a, b):
         assert np.array_equal(ra["segmentation"], rb["segmentation"]) and ra["bbox"] == rb["bbox"] and ra["area"] == rb["area"]
         assert ra["predicted_iou"] == rb["predicted_iou"] and ra["stability_score"] == rb["stability_score"]
+
+
+def test_fused_image_to_token_block_agrees_with_separate_launches(pkg, monkeypatch):
+    """bf16 decoder at the shipped width: image -> token attention, norm4 and the next layer's operands as one kernel
+    against projection + attention + projection + normalisation pass, on the real token geometry."""
+    sa = pkg.segment_anything
+    sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["geom"], seed=3)
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8)
+    pts = np.stack([rng.uniform(0, 400, 6), rng.uniform(0, 300, 6)], -1)[:, None, :]
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MARS_SAM_FUSED_I2T", flag)
+        sam = sa.sam_model_registry["geom"](state_dict=sd, device="cuda", dtype=torch.bfloat16)
+        assert all(("i2t_fused" in L) == (flag == "1") for L in sam.mask_decoder.layers)
+        pred = sa.SamPredictor(sam)
+        pred.set_image(img)
+        coords = torch.as_tensor(pred.transform.apply_coords(pts, img.shape[:2]), dtype=torch.float32, device="cuda")
+        masks, iou, low = pred.predict_torch(coords, torch.ones(6, 1, dtype=torch.int32, device="cuda"), multimask_output=True, return_logits=True)
+        res.append((masks.float().clone(), iou.float().clone(), low.float().clone()))
+    (m1, i1, l1), (m0, i0, l0) = res
+    scale = float(l0.abs().max())
+    assert float((i1 - i0).abs().max()) <= 2e-2
+    assert float((l1 - l0).abs().max()) <= 3e-2 * scale
+    assert float(((m1 > 0) != (m0 > 0)).float().mean()) < 5e-3
