@@ -335,19 +335,21 @@ int marship_sam_upscale_masks(const void* u, int64_t ldu, const void* w3, const 
                               int64_t ldh, float* masks, int64_t prompts, int G2, void* stream);
 /* The image -> token half of a two-way transformer layer at the shipped width (transformer.py:176-183, 218-240: 256 channels,
  * eight heads of 16 dims, at most eight prompt tokens; bf16 operands) as one pass over the image-side stream:
- *   q = qin Wq^T + bq;  o = attention(q, k, v) per head with scale 1/4;  y = LayerNorm(resid + o Wo^T + bo) (norm4);
- *   c0 = bf16(y + pe[token % Ni]), c1 = bf16(y), and y itself as f32 when `y` is not null.
+ *   q = (keys + key_pe) Wq^T + bq;  o = attention(q, k, v) per head with scale 1/4;  y = LayerNorm(resid + o Wo^T + bo) (norm4);
+ *   c1 = bf16(y), and y itself as f32 when `y` is not null.
+ * key_pe is the same for every prompt, so its share of q comes from a table: qbias f32 [Ni, 128] = key_pe Wq^T + bq, and
+ * qin is the bf16 copy of keys alone.
  * marship_sam_i2t_kv_operands lays the prompts' projected tokens k, v (bf16 [prompts*Tk, ld]) out as the matrix-instruction
  * operands the pass reads: kv_ops bf16 [prompts][8][64][2][8].
  * marship_sam_i2t_block: qin bf16 [prompts*Ni, ldq] (or [Ni, ldq] with q_shared: every prompt's stream is still the same);
  * wq bf16 [32][128][8]: entry (kc, r) = Wq[r][8kc .. 8kc+7]; wo bf16 [16][256][8]: entry (2h + g, r)[e] = Wo[r][16h + 8(e/4) + 4g + e%4];
- * prm f32 = bq [128], bo [256], LayerNorm weight [256], bias [256]; resid f32 [prompts*Ni, 256] (or [Ni, 256] with resid_shared);
- * pe f32 [Ni, 256]; Ni a multiple of 32.  qin / c0 and resid / y may be the same buffers. */
+ * prm f32 = bo [256], LayerNorm weight [256], bias [256]; resid f32 [prompts*Ni, 256] (or [Ni, 256] with resid_shared);
+ * Ni a multiple of 32.  qin / c1 and resid / y may be the same buffers. */
 int marship_sam_i2t_kv_operands(const void* k, int64_t ldk, const void* v, int64_t ldv, int prompts, int Tk, void* kv_ops,
                                 void* stream);
-int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void* wq, const void* wo, const float* prm,
-                          const void* kv_ops, int Tk, const float* resid, int resid_shared, const float* pe, int prompts,
-                          int Ni, float eps, float* y, void* c0, void* c1, void* stream);
+int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void* wq, const void* wo, const float* qbias,
+                          const float* prm, const void* kv_ops, int Tk, const float* resid, int resid_shared, int prompts,
+                          int Ni, float eps, float* y, void* c1, void* stream);
 /* masks[b, m, p] = sum_c hyper[b, m, c] * up[b*P + p, c], four masks a prompt, C <= 64 channels (mask_decoder.py:141-143:
  * hyper_in @ upscaled_embedding); hyper f32 [B*4, ldh], up f32 [B*P, ldu], masks f32 [B, 4, P]. */
 int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int64_t ldu, float* masks, int B,

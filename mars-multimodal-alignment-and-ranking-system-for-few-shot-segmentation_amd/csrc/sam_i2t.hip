@@ -4,8 +4,11 @@
 //
 //     q    = (keys + key_pe) Wq^T + bq                         [tokens, 128]
 //     o    = softmax(q_h k_h^T / 4) v_h   per head h           [tokens, 128]      (k, v: the prompt's projected tokens)
-//     keys = LayerNorm(keys + o Wo^T + bo)                      [tokens, 256]  f32
-//     and the two bf16 operands of the next layer, keys + key_pe and keys.
+//     keys = LayerNorm(keys + o Wo^T + bo)                      [tokens, 256]  f32, and its bf16 copy for the next products.
+//
+// key_pe is the same for every prompt and the projection is linear: q = keys Wq^T + (key_pe Wq^T + bq), and the second
+// term is a table of [image tokens, 128] made once.  So the pass reads the bf16 copy of keys alone, and no copy of
+// keys + key_pe is ever made (the token -> image attention of the next layer takes its keys the same way).
 //
 // As separate launches this is a projection, an attention kernel, a projection with residual and a normalisation pass:
 // the 4.3 GB f32 stream of 1024 prompts is read and written twice and 4 GB of q and o go through memory in between.
@@ -34,7 +37,7 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 constexpr int C = 256, W = 128, HEADS = 8, HD = 16;
 constexpr int LDS_WQ = W * C * 2, LDS_WO = C * W * 2;        // bytes
-constexpr int NPRM = W + 3 * C;                               // bq, bo, LayerNorm weight, LayerNorm bias
+constexpr int NPRM = 3 * C;                                   // bo, LayerNorm weight, LayerNorm bias
 
 __device__ __forceinline__ float halves_sum(float a) {
     const unsigned u = __builtin_bit_cast(unsigned, a);
@@ -66,18 +69,19 @@ __global__ __launch_bounds__(512) void i2t_kv_operands_kernel(const __bf16* __re
 }
 
 // qin bf16 [q_rows, ldq] (q_rows = tokens, or Ni when every prompt shares it); wq bf16 [32][128][8] and wo bf16 [16][256][8]
-// in runs of eight K, run-major (wo with its K index in slot order); prm f32 [128 + 3 * 256]; kv as above; resid f32
-// [tokens or Ni, 256]; pe f32 [Ni, 256]; y f32 [tokens, 256] or null; c0 = bf16(y + pe), c1 = bf16(y).  Eight waves a
-// workgroup, wave w of workgroup g owns the tiles [(8 g + w) per, (8 g + w + 1) per) of 32 tokens.
-// qin / c0 and resid / y may be the same buffers: a tile reads its rows before it writes them and no other tile touches them.
+// in runs of eight K, run-major (wo with its K index in slot order); qbias f32 [Ni, 128] = key_pe Wq^T + bq; prm f32
+// [3 * 256]; kv as above; resid f32 [tokens or Ni, 256]; y f32 [tokens, 256] or null; c1 = bf16(y).  Eight waves a workgroup,
+// wave w of workgroup g owns the tiles [(8 g + w) per, (8 g + w + 1) per) of 32 tokens.
+// qin / c1 and resid / y may be the same buffers: a tile reads its rows before it writes them and no other tile touches them.
+// All loads of a tile come before its first store: a wait for a load behind stores would also wait for those stores.
 __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64_t ldq, int q_shared, const __bf16* __restrict__ wq,
-                                                        const __bf16* __restrict__ wo, const float* __restrict__ prm, const bf16x8* __restrict__ kv,
-                                                        int Tk, const float* resid, int resid_shared, const float* __restrict__ pe, int Ni,
-                                                        float eps, float* y, __bf16* c0, __bf16* c1, int64_t ntiles, int64_t per) {
+                                                        const __bf16* __restrict__ wo, const float* __restrict__ qbias, const float* __restrict__ prm,
+                                                        const bf16x8* __restrict__ kv, int Tk, const float* resid, int resid_shared, int Ni,
+                                                        float eps, float* y, __bf16* c1, int64_t ntiles, int64_t per) {
     __shared__ __align__(16) unsigned char smem[LDS_WQ + LDS_WO + NPRM * 4];
     bf16x8* sWq = (bf16x8*)smem;                        // [32][128]
     bf16x8* sWo = (bf16x8*)(smem + LDS_WQ);             // [16][256]
-    float* sP = (float*)(smem + LDS_WQ + LDS_WO);       // bq [128], bo [256], ln w [256], ln b [256]
+    float* sP = (float*)(smem + LDS_WQ + LDS_WO);       // bo [256], ln w [256], ln b [256]
     for (int i = threadIdx.x; i < LDS_WQ / 16; i += 512) sWq[i] = ((const bf16x8*)wq)[i];
     for (int i = threadIdx.x; i < LDS_WO / 16; i += 512) sWo[i] = ((const bf16x8*)wo)[i];
     for (int i = threadIdx.x; i < NPRM; i += 512) sP[i] = prm[i];
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64
         asm volatile("" : "+v"(opaque));
         const bf16x8 *tWq = sWq + opaque, *tWo = sWo + opaque;
         const float* tP = sP + opaque;
-        const float *sBq = tP, *sBo = tP + W, *sLw = tP + W + C, *sLb = tP + W + 2 * C;
+        const float *sBo = tP, *sLw = tP + C, *sLb = tP + 2 * C;
         const int64_t tok = t * 32 + n;
         const int64_t b = tok / Ni;
         const int pl = (int)(tok - b * Ni);
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64
         bf16x8 ob[HEADS];                                // per head: first q, then o, as B operands
         {
             const __bf16* xp = qin + (q_shared ? (int64_t)pl : tok) * ldq + half * 8;
+            const float* qb = qbias + (int64_t)pl * W + half * 4;
             bf16x8 xb[C / 16];
 #pragma unroll
             for (int ks = 0; ks < C / 16; ++ks) xb[ks] = *(const bf16x8*)(xp + ks * 16);
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64
                 for (int ks = 0; ks < C / 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wp[ks * 2 * W], xb[ks], acc, 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 bq = *(const f32x4*)(sBq + mb * 32 + i * 8 + half * 4);
+                    const f32x4 bq = *(const f32x4*)(qb + mb * 32 + i * 8);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ob[2 * mb + (i >> 1)][4 * (i & 1) + j] = (__bf16)(acc[4 * i + j] + bq[j]);
                 }
@@ -180,37 +185,30 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64
                 sq = fmaf(acc[mb][e], acc[mb][e], sq);
             }
         const float rstd = 1.0f / sqrtf(halves_sum(sq) * (1.0f / C) + eps);
-        const float* pp = pe + (int64_t)pl * C + half * 4;
         float* yp = y ? y + tok * C + half * 4 : nullptr;
 #pragma unroll
         for (int mb = 0; mb < C / 32; ++mb)
 #pragma unroll
             for (int rpair = 0; rpair < 2; ++rpair) {
-                bf16x4 a0[2], a1[2];                     // [u]: group i = 2 rpair + u of eight channels, (y + pe) and y
+                bf16x4 a1[2];                            // [u]: group i = 2 rpair + u of eight channels
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int i = 2 * rpair + u, col = mb * 32 + i * 8;
                     const f32x4 lw = *(const f32x4*)(sLw + col + half * 4), lb = *(const f32x4*)(sLb + col + half * 4);
-                    const f32x4 pv = *(const f32x4*)(pp + col);
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[j] = fmaf(acc[mb][4 * i + j] * rstd, lw[j], lb[j]);
-                        a0[u][j] = (__bf16)(v[j] + pv[j]);
                         a1[u][j] = (__bf16)v[j];
                     }
                     if (yp) *(f32x4*)(yp + col) = v;
                 }
                 // the half-waves trade halves: the lower lane ends with the eight channels of group 2 rpair, the upper with 2 rpair + 1
-#pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    const v2i32 ai = __builtin_bit_cast(v2i32, which ? a1[0] : a0[0]), bi = __builtin_bit_cast(v2i32, which ? a1[1] : a0[1]);
-                    const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)ai[0], (unsigned)bi[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)ai[1], (unsigned)bi[1], false, false);
-                    const v4i32 o = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
-                    __bf16* dst = (which ? c1 : c0) + tok * C + mb * 32 + 8 * (2 * rpair + half);
-                    *(v4i32*)dst = o;
-                }
+                const v2i32 ai = __builtin_bit_cast(v2i32, a1[0]), bi = __builtin_bit_cast(v2i32, a1[1]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)ai[0], (unsigned)bi[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)ai[1], (unsigned)bi[1], false, false);
+                const v4i32 o = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                *(v4i32*)(c1 + tok * C + mb * 32 + 8 * (2 * rpair + half)) = o;
             }
     }
 }
@@ -227,15 +225,15 @@ extern "C" int marship_sam_i2t_kv_operands(const void* k, int64_t ldk, const voi
     return 0;
 }
 
-extern "C" int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void* wq, const void* wo, const float* prm,
-                                     const void* kv_ops, int Tk, const float* resid, int resid_shared, const float* pe, int prompts, int Ni,
-                                     float eps, float* y, void* c0, void* c1, void* stream) {
-    MARS_CHECK(qin && wq && wo && prm && kv_ops && resid && pe && c0 && c1, "sam_i2t_block: null pointer");
+extern "C" int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void* wq, const void* wo, const float* qbias,
+                                     const float* prm, const void* kv_ops, int Tk, const float* resid, int resid_shared, int prompts, int Ni,
+                                     float eps, float* y, void* c1, void* stream) {
+    MARS_CHECK(qin && wq && wo && qbias && prm && kv_ops && resid && c1, "sam_i2t_block: null pointer");
     MARS_CHECK(prompts > 0 && Ni > 0 && Ni % 32 == 0 && Tk > 0 && Tk <= 8, "sam_i2t_block: %d prompts, %d image tokens (a multiple of 32), %d prompt tokens (1 .. 8)",
                prompts, Ni, Tk);
     MARS_CHECK(ldq >= C && ldq % 8 == 0, "sam_i2t_block: row stride %lld", (long long)ldq);
-    MARS_CHECK((((uintptr_t)qin | (uintptr_t)wq | (uintptr_t)wo | (uintptr_t)prm | (uintptr_t)kv_ops | (uintptr_t)resid | (uintptr_t)pe | (uintptr_t)y |
-                 (uintptr_t)c0 | (uintptr_t)c1) % 16) == 0, "sam_i2t_block: 16-byte alignment");
+    MARS_CHECK((((uintptr_t)qin | (uintptr_t)wq | (uintptr_t)wo | (uintptr_t)prm | (uintptr_t)kv_ops | (uintptr_t)resid | (uintptr_t)qbias | (uintptr_t)y |
+                 (uintptr_t)c1) % 16) == 0, "sam_i2t_block: 16-byte alignment");
     static const int cus = [] { int dev = 0, c = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256; return c; }();
     const int64_t ntiles = (int64_t)prompts * Ni / 32;
     int64_t waves = (int64_t)cus * 8;
@@ -243,7 +241,7 @@ extern "C" int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared,
     const int64_t per = (ntiles + waves - 1) / waves;
     const unsigned grid = (unsigned)((ntiles + per * 8 - 1) / (per * 8));
     hipLaunchKernelGGL(i2t_block_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const __bf16*)qin, ldq, q_shared, (const __bf16*)wq,
-                       (const __bf16*)wo, prm, (const bf16x8*)kv_ops, Tk, resid, resid_shared, pe, Ni, eps, y, (__bf16*)c0, (__bf16*)c1, ntiles, per);
+                       (const __bf16*)wo, qbias, prm, (const bf16x8*)kv_ops, Tk, resid, resid_shared, Ni, eps, y, (__bf16*)c1, ntiles, per);
     MARS_LAUNCH_CHECK();
     return 0;
 }

@@ -763,23 +763,23 @@ def sam_i2t_kv_operands(k: torch.Tensor, v: torch.Tensor, prompts: int, Tk: int,
               "marship_sam_i2t_kv_operands")
 
 
-def sam_i2t_block(qin: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, prm: torch.Tensor, kv_ops: torch.Tensor, Tk: int, resid: torch.Tensor,
-                  pe: torch.Tensor, prompts: int, Ni: int, eps: float, y: Optional[torch.Tensor], c0: torch.Tensor, c1: torch.Tensor):
-    """Image -> token attention block + norm4 + the next layer's bf16 operands in one pass (see marship_sam_i2t_block).  qin with Ni
-    rows (instead of prompts*Ni) is shared by every prompt, and so is resid with Ni rows."""
-    _dev(qin, wq, wo, prm, kv_ops, resid, pe, y, c0, c1)
+def sam_i2t_block(qin: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, qbias: torch.Tensor, prm: torch.Tensor, kv_ops: torch.Tensor, Tk: int,
+                  resid: torch.Tensor, prompts: int, Ni: int, eps: float, y: Optional[torch.Tensor], c1: torch.Tensor):
+    """Image -> token attention block + norm4 + the bf16 copy of the result in one pass (see marship_sam_i2t_block).  qin with Ni
+    rows (instead of prompts*Ni) is shared by every prompt, and so is resid with Ni rows; qbias f32 [Ni, 128] = key_pe Wq^T + bq."""
+    _dev(qin, wq, wo, qbias, prm, kv_ops, resid, y, c1)
     rows = prompts * Ni
-    _req(qin.dtype == wq.dtype == wo.dtype == kv_ops.dtype == c0.dtype == c1.dtype == torch.bfloat16, "sam_i2t_block: bf16 operands")
-    _req(prm.dtype == resid.dtype == pe.dtype == torch.float32 and (y is None or y.dtype == torch.float32), "sam_i2t_block: f32 stream")
+    _req(qin.dtype == wq.dtype == wo.dtype == kv_ops.dtype == c1.dtype == torch.bfloat16, "sam_i2t_block: bf16 operands")
+    _req(prm.dtype == resid.dtype == qbias.dtype == torch.float32 and (y is None or y.dtype == torch.float32), "sam_i2t_block: f32 stream")
     _req(qin.dim() == 2 and qin.stride(1) == 1 and qin.shape[1] >= 256 and qin.shape[0] in (rows, Ni), "sam_i2t_block: qin")
     _req(resid.is_contiguous() and resid.dim() == 2 and resid.shape[1] == 256 and resid.shape[0] in (rows, Ni), "sam_i2t_block: resid")
-    _req(pe.is_contiguous() and pe.numel() == Ni * 256 and prm.is_contiguous() and prm.numel() == 128 + 3 * 256, "sam_i2t_block: pe / prm")
+    _req(qbias.is_contiguous() and qbias.numel() == Ni * 128 and prm.is_contiguous() and prm.numel() == 3 * 256, "sam_i2t_block: qbias / prm")
     _req(wq.is_contiguous() and wq.numel() == 128 * 256 and wo.is_contiguous() and wo.numel() == 256 * 128, "sam_i2t_block: weights")
     _req(kv_ops.is_contiguous() and kv_ops.numel() >= prompts * 8 * 64 * 16, "sam_i2t_block: kv_ops")
-    for t in (c0, c1) + ((y,) if y is not None else ()):
+    for t in (c1,) + ((y,) if y is not None else ()):
         _req(t.is_contiguous() and t.numel() == rows * 256, "sam_i2t_block: outputs")
-    hip.check(hip.lib().marship_sam_i2t_block(ptr(qin), qin.stride(0), int(qin.shape[0] == Ni and prompts > 1), ptr(wq), ptr(wo), ptr(prm), ptr(kv_ops), Tk,
-                                              ptr(resid), int(resid.shape[0] == Ni and prompts > 1), ptr(pe), prompts, Ni, eps, ptr(y), ptr(c0), ptr(c1),
+    hip.check(hip.lib().marship_sam_i2t_block(ptr(qin), qin.stride(0), int(qin.shape[0] == Ni and prompts > 1), ptr(wq), ptr(wo), ptr(qbias), ptr(prm),
+                                              ptr(kv_ops), Tk, ptr(resid), int(resid.shape[0] == Ni and prompts > 1), prompts, Ni, eps, ptr(y), ptr(c1),
                                               stream()), "marship_sam_i2t_block")
 
 

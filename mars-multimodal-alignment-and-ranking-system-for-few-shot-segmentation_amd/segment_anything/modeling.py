@@ -380,8 +380,7 @@ class MaskDecoder:
                 L["i2t_fused"] = dict(
                     wq=wq.view(128, 32, 8).permute(1, 0, 2).contiguous().to(dev, torch.bfloat16),
                     wo=wo[:, slot].view(256, 16, 8).permute(1, 0, 2).contiguous().to(dev, torch.bfloat16),
-                    prm=torch.cat([sd[pi + ".q_proj.bias"].float(), sd[pi + ".out_proj.bias"].float(), sd[p + ".norm4.weight"].float(),
-                                   sd[p + ".norm4.bias"].float()]).contiguous().to(dev))
+                    prm=torch.cat([sd[pi + ".out_proj.bias"].float(), sd[p + ".norm4.weight"].float(), sd[p + ".norm4.bias"].float()]).contiguous().to(dev))
             self.layers.append(L)
         self.final = _DecAttn(sd, pre + ".final_attn_token_to_image", C, cfg.dec_heads, 2, dev, dtype)
         self.nf = ln(pre + ".norm_final_attn")
@@ -421,16 +420,21 @@ class MaskDecoder:
         return b
 
     def _attention(self, A: _DecAttn, tag: str, q_in, k_in, v_in, nb: int, Tq: int, Tk: int, out: torch.Tensor, residual,
-                   q_shared: bool = False, kv_shared: bool = False):
+                   q_shared: bool = False, kv_shared: bool = False, k_pe: Optional[torch.Tensor] = None):
         """transformer.py:218-240: q_in [nb*Tq, C], k_in / v_in [nb*Tk, C] in the compute dtype -> out f32 (+ residual).
         ``q_shared``: q_in and residual hold one set of Tq rows for every prompt; ``kv_shared``: k_in / v_in one set of Tk rows
-        (the image side of the first layer: projected once, not once a prompt)."""
+        (the image side of the first layer: projected once, not once a prompt).  ``k_pe`` f32 [Tk, H*hd]: k_in lacks the
+        positional term; its projection (with the bias) is this table, the same for every prompt."""
         if A.small and (Tk <= 16 or Tq <= 16):
             W = A.H * A.hd
             nq, nk = (1 if q_shared else nb), (1 if kv_shared else nb)
             q = self._buf(tag + "qs", (nq * Tq, W)); k = self._buf(tag + "ks", (nk * Tk, W)); v = self._buf(tag + "vs", (nk * Tk, W))
             ops.linear(q_in, A.qs.w, q, bias=A.qs.b)
-            ops.linear(k_in, A.ks.w, k, bias=A.ks.b)
+            if k_pe is not None:
+                ops.gemm(k_in, A.ks.w, k, Tk, W, A.ks.w.shape[1], lda=k_in.stride(0), ldb=A.ks.w.stride(0), ldc=W, nb0=nk, sA=(Tk * k_in.stride(0), 0),
+                         sC=(Tk * W, 0), residual=k_pe, ldr=W, sR=(0, 0))
+            else:
+                ops.linear(k_in, A.ks.w, k, bias=A.ks.b)
             ops.linear(v_in, A.vs.w, v, bias=A.vs.b)
             Wp = _pad_to(W, 64)
             o = self._buf(tag + "os", (nb * Tq, Wp))                     # (K of the output projection, padded like its weight)
@@ -442,7 +446,7 @@ class MaskDecoder:
             else:
                 ops.linear(o, A.os.w, out, bias=A.os.b, residual=residual)
             return
-        assert not (q_shared or kv_shared)
+        assert not (q_shared or kv_shared) and k_pe is None
         W = A.H * A.hdp
         q = self._buf(tag + "q", (nb * Tq, W)); k = self._buf(tag + "k", (nb * Tk, W)); v = self._buf(tag + "v", (nb * Tk, W))
         ops.linear(q_in, A.q.w, q, bias=A.q.b)
@@ -451,6 +455,23 @@ class MaskDecoder:
         o = self._buf(tag + "o", (nb * Tq, W))
         self._attn.run(q, 0, k, 0, v, 0, o, nb, A.H, Tq, Tk, A.hdp, 1.0 / math.sqrt(A.hd))
         ops.linear(o, A.o.w, out, bias=A.o.b, residual=residual)
+
+    def _pe_terms(self, pe_tokens: torch.Tensor) -> Dict[tuple, torch.Tensor]:
+        """key_pe W^T + b (f32 [Ni, 128]) for the projections that read keys + key_pe: ("k", i) the key projection of layer
+        i's token -> image attention (i = number of layers: the final attention), ("q", i) the query projection of layer i's
+        image -> token attention.  key_pe belongs to the model, not to the image: made at first use."""
+        key = (pe_tokens.data_ptr(), tuple(pe_tokens.shape))
+        if getattr(self, "_pe_key", None) != key:
+            ped = pe_tokens.to(self.dtype)
+            terms = {}
+            for i, L in enumerate(self.layers):
+                for name, lin in (("k", L["t2i"].ks), ("q", L["i2t"].qs)):
+                    t = terms[(name, i)] = torch.empty(pe_tokens.shape[0], lin.w.shape[0], dtype=torch.float32, device=self.device)
+                    ops.linear(ped, lin.w, t, bias=lin.b)
+            t = terms[("k", len(self.layers))] = torch.empty(pe_tokens.shape[0], self.final.ks.w.shape[0], dtype=torch.float32, device=self.device)
+            ops.linear(ped, self.final.ks.w, t, bias=self.final.ks.b)
+            self._pe_key, self._pe_tab = key, terms
+        return self._pe_tab
 
     def predict_masks(self, feats_tokens: torch.Tensor, dense_pe_tokens: torch.Tensor, sparse: torch.Tensor, no_mask: torch.Tensor,
                       dense_tokens: Optional[torch.Tensor] = None):
@@ -491,8 +512,12 @@ class MaskDecoder:
         pe2 = pe.view(B * Nt, C)
         # kd = keys + key_pe and vd = keys in the compute dtype, made once per state of the image stream: here, and by
         # the pass that applies norm4 at the end of each layer
+        # With the image -> token block as one kernel (ops.sam_i2t_block) no copy of keys + key_pe exists after the first
+        # layer: the positional term enters the projections that would have read it as a table, made once per model.
+        fused_i2t = all("i2t_fused" in L and L["t2i"].small for L in self.layers) and self.final.small and Nt <= 8 and Ni % 32 == 0
+        pe_terms = self._pe_terms(dense_pe_tokens) if fused_i2t else None
         if not share0:
-            ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens)
+            ops.stream_copies(Kf, None if fused_i2t else kd, vd, add=None if fused_i2t else dense_pe_tokens)
 
         def ln(x, wb, rows):
             ops.layernorm(x[:rows], wb[0], wb[1], x[:rows], 1e-5)
@@ -511,6 +536,8 @@ class MaskDecoder:
             ops.add_cast(Q, pe2, qd)
             if share0 and i == 0:
                 self._attention(L["t2i"], "t2i", qd, kd0, vd0, B, Nt, Ni, Q, Q, kv_shared=True)
+            elif fused_i2t:
+                self._attention(L["t2i"], "t2i", qd, vd, vd, B, Nt, Ni, Q, Q, k_pe=pe_terms[("k", i)])
             else:
                 self._attention(L["t2i"], "t2i", qd, kd, vd, B, Nt, Ni, Q, Q)
             ln(Q, L["n2"], B * Nt)
@@ -523,7 +550,7 @@ class MaskDecoder:
             ops.add_cast(Q, pe2, qd)
             ops.add_cast(Q, None, td)
             last = i + 1 == len(self.layers)
-            if "i2t_fused" in L and Nt <= 8 and Ni % 32 == 0:
+            if fused_i2t:
                 A, Fz = L["i2t"], L["i2t_fused"]
                 k = self._buf("i2tks", (B * Nt, 128)); v = self._buf("i2tvs", (B * Nt, 128))
                 ops.linear(qd, A.ks.w, k, bias=A.ks.b)
@@ -531,8 +558,8 @@ class MaskDecoder:
                 kvo = self._buf("i2tkv", (B, 8, 64, 2, 8))
                 ops.sam_i2t_kv_operands(k, v, B, Nt, kvo)
                 first0 = share0 and i == 0
-                ops.sam_i2t_block(kd0 if first0 else kd, Fz["wq"], Fz["wo"], Fz["prm"], kvo, Nt, src0 if first0 else Kf, dense_pe_tokens, B, Ni,
-                                  1e-5, None if last else Kf, kd, vd)
+                ops.sam_i2t_block(vd0 if first0 else vd, Fz["wq"], Fz["wo"], pe_terms[("q", i)], Fz["prm"], kvo, Nt, src0 if first0 else Kf, B, Ni,
+                                  1e-5, None if last else Kf, vd)
                 continue
             if share0 and i == 0:
                 self._attention(L["i2t"], "i2t", kd0, qd, td, B, Ni, Nt, Kf, src0, q_shared=True)
@@ -541,7 +568,10 @@ class MaskDecoder:
             ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens, norm=L["n4"], eps=1e-5,
                               write_back=i + 1 < len(self.layers))        # (nothing reads the f32 stream after the last layer)
         ops.add_cast(Q, pe2, qd)
-        self._attention(self.final, "fin", qd, kd, vd, B, Nt, Ni, Q, Q)
+        if fused_i2t:
+            self._attention(self.final, "fin", qd, vd, vd, B, Nt, Ni, Q, Q, k_pe=pe_terms[("k", len(self.layers))])
+        else:
+            self._attention(self.final, "fin", qd, kd, vd, B, Nt, Ni, Q, Q)
         ln(Q, self.nf, B * Nt)
         hs = Q.view(B, Nt, C)
         # upscaling: ConvT(2,2) -> LayerNorm2d -> GELU -> ConvT(2,2) -> GELU, written straight into the
