@@ -350,6 +350,9 @@ class _DecAttn:
         if self.small:
             mks = lambda n: Lin(sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"], dtype, device)
             self.qs, self.ks, self.vs, self.os = mks("q_proj"), mks("k_proj"), mks("v_proj"), mks("out_proj")
+            # key and value projections of one input as one product (rows: keys, then values)
+            self.kvs = Lin(torch.cat([sd[f"{p}.k_proj.weight"], sd[f"{p}.v_proj.weight"]], 0),
+                           torch.cat([sd[f"{p}.k_proj.bias"], sd[f"{p}.v_proj.bias"]], 0), dtype, device)
 
 
 class MaskDecoder:
@@ -423,19 +426,23 @@ class MaskDecoder:
                    q_shared: bool = False, kv_shared: bool = False, k_pe: Optional[torch.Tensor] = None):
         """transformer.py:218-240: q_in [nb*Tq, C], k_in / v_in [nb*Tk, C] in the compute dtype -> out f32 (+ residual).
         ``q_shared``: q_in and residual hold one set of Tq rows for every prompt; ``kv_shared``: k_in / v_in one set of Tk rows
-        (the image side of the first layer: projected once, not once a prompt).  ``k_pe`` f32 [Tk, H*hd]: k_in lacks the
-        positional term; its projection (with the bias) is this table, the same for every prompt."""
+        (the image side of the first layer: projected once, not once a prompt).  ``k_pe`` f32 [Tk, 2*H*hd]: k_in (which is also
+        v_in) lacks the positional term; columns [0, H*hd) of the table are its key projection with the bias, the rest the
+        bias of the value projection: keys and values come from one product."""
         if A.small and (Tk <= 16 or Tq <= 16):
             W = A.H * A.hd
             nq, nk = (1 if q_shared else nb), (1 if kv_shared else nb)
-            q = self._buf(tag + "qs", (nq * Tq, W)); k = self._buf(tag + "ks", (nk * Tk, W)); v = self._buf(tag + "vs", (nk * Tk, W))
+            q = self._buf(tag + "qs", (nq * Tq, W))
             ops.linear(q_in, A.qs.w, q, bias=A.qs.b)
-            if k_pe is not None:
-                ops.gemm(k_in, A.ks.w, k, Tk, W, A.ks.w.shape[1], lda=k_in.stride(0), ldb=A.ks.w.stride(0), ldc=W, nb0=nk, sA=(Tk * k_in.stride(0), 0),
-                         sC=(Tk * W, 0), residual=k_pe, ldr=W, sR=(0, 0))
+            if k_pe is not None:                 # k_in is v_in: one product with 2 W columns, k_pe holds both bias terms
+                kv = self._buf(tag + "kvs", (nk * Tk, 2 * W))
+                ops.gemm(k_in, A.kvs.w, kv, Tk, 2 * W, A.kvs.w.shape[1], lda=k_in.stride(0), ldb=A.kvs.w.stride(0), ldc=2 * W, nb0=nk,
+                         sA=(Tk * k_in.stride(0), 0), sC=(Tk * 2 * W, 0), residual=k_pe, ldr=2 * W, sR=(0, 0))
+                k, v = kv[:, :W], kv[:, W:]
             else:
+                k = self._buf(tag + "ks", (nk * Tk, W)); v = self._buf(tag + "vs", (nk * Tk, W))
                 ops.linear(k_in, A.ks.w, k, bias=A.ks.b)
-            ops.linear(v_in, A.vs.w, v, bias=A.vs.b)
+                ops.linear(v_in, A.vs.w, v, bias=A.vs.b)
             Wp = _pad_to(W, 64)
             o = self._buf(tag + "os", (nb * Tq, Wp))                     # (K of the output projection, padded like its weight)
             ops.attn_small(q, k, v, o, nb, A.H, A.hd, Tq, Tk, 1.0 / math.sqrt(A.hd), q_shared=q_shared, kv_shared=kv_shared)
@@ -457,19 +464,22 @@ class MaskDecoder:
         ops.linear(o, A.o.w, out, bias=A.o.b, residual=residual)
 
     def _pe_terms(self, pe_tokens: torch.Tensor) -> Dict[tuple, torch.Tensor]:
-        """key_pe W^T + b (f32 [Ni, 128]) for the projections that read keys + key_pe: ("k", i) the key projection of layer
-        i's token -> image attention (i = number of layers: the final attention), ("q", i) the query projection of layer i's
-        image -> token attention.  key_pe belongs to the model, not to the image: made at first use."""
+        """key_pe W^T + b for the projections that read keys + key_pe: ("q", i) f32 [Ni, 128] the query projection of layer i's
+        image -> token attention; ("k", i) f32 [Ni, 256] the key projection of layer i's token -> image attention (i = number
+        of layers: the final attention) followed by the value projection's bias, for the joint key / value product.
+        key_pe belongs to the model, not to the image: made at first use."""
         key = (pe_tokens.data_ptr(), tuple(pe_tokens.shape))
         if getattr(self, "_pe_key", None) != key:
             ped = pe_tokens.to(self.dtype)
             terms = {}
             for i, L in enumerate(self.layers):
-                for name, lin in (("k", L["t2i"].ks), ("q", L["i2t"].qs)):
-                    t = terms[(name, i)] = torch.empty(pe_tokens.shape[0], lin.w.shape[0], dtype=torch.float32, device=self.device)
-                    ops.linear(ped, lin.w, t, bias=lin.b)
-            t = terms[("k", len(self.layers))] = torch.empty(pe_tokens.shape[0], self.final.ks.w.shape[0], dtype=torch.float32, device=self.device)
-            ops.linear(ped, self.final.ks.w, t, bias=self.final.ks.b)
+                t = terms[("q", i)] = torch.empty(pe_tokens.shape[0], L["i2t"].qs.w.shape[0], dtype=torch.float32, device=self.device)
+                ops.linear(ped, L["i2t"].qs.w, t, bias=L["i2t"].qs.b)
+            for i, A in enumerate([L["t2i"] for L in self.layers] + [self.final]):
+                W = A.ks.w.shape[0]
+                t = terms[("k", i)] = torch.empty(pe_tokens.shape[0], 2 * W, dtype=torch.float32, device=self.device)
+                ops.linear(ped, A.ks.w, t[:, :W], bias=A.ks.b)
+                t[:, W:] = A.vs.b
             self._pe_key, self._pe_tab = key, terms
         return self._pe_tab
 
