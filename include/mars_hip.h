@@ -366,7 +366,7 @@ typedef struct MarsAxisTable { const int32_t* lo; const int32_t* size; const flo
  * low-resolution ones [.., L, L] a band of `band` output rows at a time (first along x with tx [W entries], then along y
  * with ty [H entries], the order and sums of marship_resample_axis) and never stored.  Plane p of the input starts at
  * low + (p / nm) * stride_b + (p % nm) * stride_c.  max_rows = the most source rows any band reads (the caller computes it
- * from ty; max_rows * W floats must fit in 64 KB of LDS).
+ * from ty; max_rows * (L + W) floats must fit in 64 KB of LDS).
  * marship_resample_mask_stats: stats[p] of marship_mask_stats for planes 0 .. n-1.
  * marship_resample_threshold: out[i] f32 [H, W] = (logits of plane sel[i] (or i when sel is NULL) > thr) as 0 / 1. */
 int marship_resample_mask_stats(const float* low, int64_t stride_b, int64_t stride_c, int nm, int n, int L, int H, int W,

@@ -414,19 +414,41 @@ __global__ __launch_bounds__(256) void threshold_masks_kernel(const float* __res
 }
 
 // Sam.postprocess_masks (two bilinear passes and a crop, composed into one banded table an axis) evaluated on the fly
-// from the low-resolution logits, a band of output rows at a time: the source rows the band needs are resampled along x
-// into LDS, then along y out of LDS - the two sums of resample_axis_kernel in the same order, so the values are the
+// from the low-resolution logits, a band of output rows at a time: the source rows the band needs are copied to LDS,
+// resampled along x into a second LDS array, then along y out of that - the two sums of resample_axis_kernel in the same order, so the values are the
 // ones the two-pass form writes - and consumed in place: by the mask statistics (STATS: a workgroup walks all bands of
 // one plane) or by the threshold (a workgroup owns one band of one selected plane and writes 0 / 1).  The image-size
 // logits never exist in memory.
 struct AxisTable { const int32_t* lo; const int32_t* size; const float* w; int kmax; };
 
-template <bool STATS>
+// KT: taps unrolled per sum (tables with kmax <= KT; weights past an output's size are zero in the table and the index is
+// clamped, so the extra terms add an exact zero); KT = 0: loops of the table's own length.
+template <int KT>
+__device__ __forceinline__ float banded_sum(const float* __restrict__ v, int stride, int m0, int ms, int last, const float* __restrict__ w, int kmax) {
+    float acc = 0.f;
+    if constexpr (KT > 0) {
+        float x[KT], wk[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {                   // all reads requested before the first is used
+            x[k] = v[min(m0 + k, last) * stride];
+            wk[k] = k < kmax ? w[k] : 0.f;                // (a row of the table holds kmax weights)
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc = k == 0 ? x[0] * wk[0] : acc + x[k] * wk[k];
+    } else {
+        for (int k = 0; k < ms; ++k) acc = k == 0 ? v[m0 * stride] * w[0] : acc + v[(m0 + k) * stride] * w[k];
+    }
+    return acc;
+}
+
+template <bool STATS, int KT>
 __global__ __launch_bounds__(256) void resample_bands_kernel(const float* __restrict__ low, int64_t stride_b, int64_t stride_c, int nm,
                                                              const int32_t* __restrict__ sel, int L, int H, int W, AxisTable tx, AxisTable ty,
                                                              int band, int max_rows, float thr, float off, int32_t* __restrict__ stats,
                                                              float* __restrict__ out) {
-    extern __shared__ float tmp[];                       // [max_rows][W]
+    extern __shared__ float bands_lds[];
+    float* srow = bands_lds;                             // [max_rows][L]: the source rows of the band
+    float* tmp = bands_lds + (size_t)max_rows * L;       // [max_rows][W]: those rows resampled along x
     __shared__ int sr[2];
     __shared__ int sh[6][4];
     const int slot = STATS ? blockIdx.x : blockIdx.y;
@@ -436,7 +458,7 @@ __global__ __launch_bounds__(256) void resample_bands_kernel(const float* __rest
     const int nb = (H + band - 1) / band;
     for (int b = STATS ? 0 : blockIdx.x; b < (STATS ? nb : blockIdx.x + 1); ++b) {
         const int ya = b * band, yb = min(H, ya + band);
-        __syncthreads();                                  // (the previous band is done with tmp and sr)
+        __syncthreads();                                  // (the previous band is done with the LDS rows and sr)
         if (threadIdx.x < 64) {                           // source rows [r0, r1) of this band
             int r0 = L, r1 = 0;
             for (int y = ya + (int)threadIdx.x; y < yb; y += 64) {
@@ -452,23 +474,25 @@ __global__ __launch_bounds__(256) void resample_bands_kernel(const float* __rest
         }
         __syncthreads();
         const int r0 = sr[0], nr = max(sr[1] - r0, 0);
+        // the rows are consecutive in memory: one coalesced copy
+        const float* sp = src + (int64_t)r0 * L;
+        if ((L & 3) == 0 && ((uintptr_t)sp & 15) == 0) {
+            for (int i = threadIdx.x; i < nr * L / 4; i += 256) ((f32x4*)srow)[i] = ((const f32x4*)sp)[i];
+        } else {
+            for (int i = threadIdx.x; i < nr * L; i += 256) srow[i] = sp[i];
+        }
+        __syncthreads();
         for (int x = threadIdx.x; x < W; x += 256) {
             const int m0 = tx.lo[x], ms = tx.size[x];
             const float* w = tx.w + (int64_t)x * tx.kmax;
-            for (int r = 0; r < nr; ++r) {
-                const float* sp = src + (int64_t)(r0 + r) * L + m0;
-                float acc = 0.f;
-                for (int k = 0; k < ms; ++k) acc = k == 0 ? sp[0] * w[0] : acc + sp[k] * w[k];
-                tmp[r * W + x] = acc;
-            }
+            for (int r = 0; r < nr; ++r) tmp[r * W + x] = banded_sum<KT>(srow + r * L, 1, m0, ms, L - 1, w, tx.kmax);
         }
         __syncthreads();
         for (int y = ya; y < yb; ++y) {
             const int m0 = ty.lo[y] - r0, ms = min(ty.size[y], nr - m0);
             const float* w = ty.w + (int64_t)y * ty.kmax;
             for (int x = threadIdx.x; x < W; x += 256) {
-                float acc = 0.f;
-                for (int k = 0; k < ms; ++k) acc = k == 0 ? tmp[m0 * W + x] * w[0] : acc + tmp[(m0 + k) * W + x] * w[k];
+                const float acc = banded_sum<KT>(tmp + x, W, m0, ms, nr - 1, w, ty.kmax);
                 if (STATS) {
                     hi += acc > thr + off;
                     lo += acc > thr - off;
@@ -505,7 +529,8 @@ int check_bands(const char* what, const float* low, int nm, int L, int H, int W,
     MARS_CHECK(low && tx && ty && tx->lo && tx->size && tx->w && ty->lo && ty->size && ty->w, "%s: null pointer", what);
     MARS_CHECK(nm > 0 && L > 0 && H > 0 && W > 0 && tx->kmax > 0 && ty->kmax > 0, "%s: bad shape", what);
     MARS_CHECK(band > 0 && max_rows > 0 && max_rows <= L, "%s: band %d / rows %d", what, band, max_rows);
-    MARS_CHECK((size_t)max_rows * W * sizeof(float) <= 64 * 1024, "%s: %d source rows of %d samples do not fit in LDS; use a smaller band", what, max_rows, W);
+    MARS_CHECK((size_t)max_rows * (W + L) * sizeof(float) <= 64 * 1024, "%s: %d source rows of %d + %d samples do not fit in LDS; use a smaller band", what,
+               max_rows, L, W);
     return 0;
 }
 
@@ -517,8 +542,13 @@ extern "C" int marship_resample_mask_stats(const float* low, int64_t stride_b, i
     if (check_bands("resample_mask_stats", low, nm, L, H, W, tx, ty, band, max_rows)) return -1;
     MARS_CHECK(stats && n > 0, "resample_mask_stats: bad arguments");
     const AxisTable ax = {tx->lo, tx->size, tx->w, tx->kmax}, ay = {ty->lo, ty->size, ty->w, ty->kmax};
-    hipLaunchKernelGGL(resample_bands_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)max_rows * W * sizeof(float), (hipStream_t)stream, low,
-                       stride_b, stride_c, nm, (const int32_t*)nullptr, L, H, W, ax, ay, band, max_rows, thr, off, stats, (float*)nullptr);
+    const size_t shm = (size_t)max_rows * (W + L) * sizeof(float);
+    const int kt = ax.kmax <= 4 && ay.kmax <= 4 ? 4 : ax.kmax <= 8 && ay.kmax <= 8 ? 8 : 0;
+#define MARS_BANDS(KT)                                                                                                                       \
+    hipLaunchKernelGGL((resample_bands_kernel<true, KT>), dim3((unsigned)n), dim3(256), shm, (hipStream_t)stream, low, stride_b, stride_c, nm,    \
+                       (const int32_t*)nullptr, L, H, W, ax, ay, band, max_rows, thr, off, stats, (float*)nullptr)
+    if (kt == 4) MARS_BANDS(4); else if (kt == 8) MARS_BANDS(8); else MARS_BANDS(0);
+#undef MARS_BANDS
     MARS_LAUNCH_CHECK();
     return 0;
 }
@@ -529,9 +559,14 @@ extern "C" int marship_resample_threshold(const float* low, int64_t stride_b, in
     if (check_bands("resample_threshold", low, nm, L, H, W, tx, ty, band, max_rows)) return -1;
     MARS_CHECK(out && nsel > 0 && nsel <= 65535, "resample_threshold: %d planes (1 .. 65535 a launch)", nsel);
     const AxisTable ax = {tx->lo, tx->size, tx->w, tx->kmax}, ay = {ty->lo, ty->size, ty->w, ty->kmax};
-    hipLaunchKernelGGL(resample_bands_kernel<false>, dim3((unsigned)((H + band - 1) / band), (unsigned)nsel), dim3(256),
-                       (size_t)max_rows * W * sizeof(float), (hipStream_t)stream, low, stride_b, stride_c, nm, sel, L, H, W, ax, ay, band, max_rows, thr,
-                       0.f, (int32_t*)nullptr, out);
+    const size_t shm = (size_t)max_rows * (W + L) * sizeof(float);
+    const dim3 grid((unsigned)((H + band - 1) / band), (unsigned)nsel);
+    const int kt = ax.kmax <= 4 && ay.kmax <= 4 ? 4 : ax.kmax <= 8 && ay.kmax <= 8 ? 8 : 0;
+#define MARS_BANDS(KT)                                                                                                                       \
+    hipLaunchKernelGGL((resample_bands_kernel<false, KT>), grid, dim3(256), shm, (hipStream_t)stream, low, stride_b, stride_c, nm, sel, L, H, W, ax, ay, \
+                       band, max_rows, thr, 0.f, (int32_t*)nullptr, out)
+    if (kt == 4) MARS_BANDS(4); else if (kt == 8) MARS_BANDS(8); else MARS_BANDS(0);
+#undef MARS_BANDS
     MARS_LAUNCH_CHECK();
     return 0;
 }

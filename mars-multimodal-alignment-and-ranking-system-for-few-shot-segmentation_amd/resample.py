@@ -162,8 +162,9 @@ def sam_postprocess_table(low_size: int, img_size: int, input_len: int, orig_len
 
 
 def band_plan(table_y, in_rows: int, width: int, lds_bytes: int = 64 * 1024, bands=(16, 8, 4, 2, 1)):
-    """For the banded evaluation of a two-axis resampling (x into LDS, then y out of LDS): the largest band of output rows
-    whose source rows (of ``width`` f32 samples each) fit in ``lds_bytes``.  table_y = (lo, size, weights) of the y axis on
+    """For the banded evaluation of a two-axis resampling of square planes of side ``in_rows`` (source rows into LDS, x into a
+    second LDS array, then y out of that): the largest band of output rows whose source rows (``in_rows`` + ``width`` f32
+    samples each) fit in ``lds_bytes``.  table_y = (lo, size, weights) of the y axis on
     the host.  Returns (band, max_rows) or None."""
     lo, size = np.asarray(table_y[0], np.int64), np.asarray(table_y[1], np.int64)
     if lo.size == 0 or int((lo + size).max()) > in_rows or int(lo.min()) < 0:
@@ -172,6 +173,6 @@ def band_plan(table_y, in_rows: int, width: int, lds_bytes: int = 64 * 1024, ban
         rows = 1
         for a in range(0, lo.size, band):
             rows = max(rows, int((lo[a:a + band] + size[a:a + band]).max() - lo[a:a + band].min()))
-        if rows * width * 4 <= lds_bytes:
+        if rows * (width + in_rows) * 4 <= lds_bytes:
             return band, rows
     return None
