@@ -2,6 +2,7 @@
 // row gathers (window partition / un-partition, 3x3 neighbourhoods, pixel shuffles), the decomposed
 // relative-position bias, a row softmax with that bias, the random-Fourier position code, and the
 // per-mask statistics of the automatic mask generator.
+#include <type_traits>
 #include "common.h"
 #include "../../include/mars_hip.h"
 
@@ -48,15 +49,61 @@ __global__ __launch_bounds__(256) void relpos_bias_kernel(const T* __restrict__ 
     float* qs = shm;
     float* ts = shm + nr * pitch;
     const float* table = along_w ? Rw + (int64_t)fixed * Wk * hd : Rh + (int64_t)fixed * Hk * hd;
-    for (int i = threadIdx.x; i < nr * hd; i += 256) {
-        const int r = i / hd, d = i % hd;
-        const int t = along_w ? r * gw + fixed : fixed * gw + r;
-        qs[r * pitch + d] = ld_as_f32<T>(qkv + (b * Tn + t) * ld + (int64_t)head * hdp + d);
+    const int nt = blockDim.x;
+    if (sizeof(T) == 2 && (hd & 7) == 0 && (hdp & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)table & 15) == 0) {
+        // 16-byte pieces: eight values of a query row, four of a table row
+        const int qp = hd >> 3, tp = hd >> 2;
+        for (int i = threadIdx.x; i < nr * qp; i += nt) {
+            const int r = i / qp, d = (i - r * qp) * 8;
+            const int t = along_w ? r * gw + fixed : fixed * gw + r;
+            const bf16x8 v = *(const bf16x8*)((const __bf16*)qkv + (b * Tn + t) * ld + (int64_t)head * hdp + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qs[r * pitch + d + e] = (float)v[e];
+        }
+        for (int i = threadIdx.x; i < nk * tp; i += nt) {
+            const int r = i / tp, d = (i - r * tp) * 4;
+            const f32x4 v = ((const f32x4*)table)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ts[r * pitch + d + e] = v[e];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nr * hd; i += nt) {
+            const int r = i / hd, d = i % hd;
+            const int t = along_w ? r * gw + fixed : fixed * gw + r;
+            qs[r * pitch + d] = ld_as_f32<T>(qkv + (b * Tn + t) * ld + (int64_t)head * hdp + d);
+        }
+        for (int i = threadIdx.x; i < nk * hd; i += nt) ts[(i / hd) * pitch + i % hd] = table[i];
     }
-    for (int i = threadIdx.x; i < nk * hd; i += 256) ts[(i / hd) * pitch + i % hd] = table[i];
     __syncthreads();
     float* out = along_w ? rel_w : rel_h;
-    for (int o = threadIdx.x; o < nr * nk; o += 256) {
+    // TS x TS outputs a thread: 2 TS LDS reads per TS^2 multiply-adds (every sum still runs over d in increasing order)
+    auto tiled = [&](auto ts_tag) {
+        constexpr int TS = decltype(ts_tag)::value;
+        const int tk = nk / TS;
+        for (int tile = threadIdx.x; tile < (nr / TS) * tk; tile += nt) {
+            const int r4 = (tile / tk) * TS, k4 = (tile % tk) * TS;
+            float acc[TS][TS] = {};
+#pragma unroll 4
+            for (int d = 0; d < hd; ++d) {
+                float qv[TS], tv[TS];
+#pragma unroll
+                for (int i = 0; i < TS; ++i) { qv[i] = qs[(r4 + i) * pitch + d]; tv[i] = ts[(k4 + i) * pitch + d]; }
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+#pragma unroll
+                    for (int j = 0; j < TS; ++j) acc[i][j] = fmaf(qv[i], tv[j], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                const int t = along_w ? (r4 + i) * gw + fixed : fixed * gw + r4 + i;
+#pragma unroll
+                for (int j = 0; j < TS; ++j) out[(bh * Tn + t) * nk + k4 + j] = acc[i][j];
+            }
+        }
+    };
+    if ((nr & 3) == 0 && (nk & 3) == 0) { tiled(std::integral_constant<int, 4>{}); return; }
+    if ((nr & 1) == 0 && (nk & 1) == 0) { tiled(std::integral_constant<int, 2>{}); return; }
+    for (int o = threadIdx.x; o < nr * nk; o += nt) {
         const int r = o / nk, k = o % nk;
         const float* q = qs + r * pitch;
         const float* tb = ts + k * pitch;
