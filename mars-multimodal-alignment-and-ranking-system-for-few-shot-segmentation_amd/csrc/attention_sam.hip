@@ -41,43 +41,47 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 a, f32x4 b) {
 // HD: padded head dim (64 or 128); QB: 16-query blocks per wave; four waves per workgroup.  K / V tiles of 64 keys
 // are double buffered and filled by LDS-DMA; a tile's last fragments are in registers before the fill of the next
 // tile starts (hipcc would otherwise drain the DMAs in front of every LDS read that follows one).
-template <int HD, int QB, bool ROWTILE>
-__global__ __launch_bounds__(256, 2) void sam_attn_kernel(const __bf16* __restrict__ qkv, int64_t ld, __bf16* __restrict__ O,
+// ALLKV (T <= 4 tiles: the 14 x 14 windows): one workgroup of NW waves per (image, head); all of K and V is brought into
+// LDS by one burst of fills and one barrier, then every wave walks its 16-query blocks over the resident tiles.  With
+// four 64-query workgroups per (window, head), each re-filling the same 196 keys tile by tile behind a barrier, the
+// windowed blocks spent their time waiting: four dependent fill latencies for a few hundred matrix instructions.
+template <int HD, int QB, bool ROWTILE, int NW = 4, bool ALLKV = false>
+__global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const __bf16* __restrict__ qkv, int64_t ld, __bf16* __restrict__ O,
                                                           int64_t ldo, const float* __restrict__ rel_h,
                                                           const float* __restrict__ rel_w, int T, int H, int Hk, int Wk,
                                                           float c2) {
-    constexpr int NW = 4, ROWB = HD * 2, KS = HD / 32, DM = HD / 16, QPB = NW * QB * 16;
+    constexpr int ROWB = HD * 2, KS = HD / 32, DM = HD / 16, QPB = NW * QB * 16;
+    static_assert(!ALLKV || QB == 1, "the resident form walks one 16-query block a wave at a time");
     constexpr int PPO = KT * ROWB / 1024;          // 1-KiB DMA pieces per operand tile
     constexpr int PPW = 2 * PPO / NW;              // pieces per wave and tile
     constexpr int RPP = 1024 / ROWB, LPR = ROWB / 16;     // key rows per piece, lanes per key row
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KT * ROWB];      // [buf][K|V]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ALLKV ? 4 : 2][2][KT * ROWB];      // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r16 = lane & 15;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int q0 = blockIdx.x * QPB + wave * (QB * 16);
+    int q0 = blockIdx.x * QPB + wave * (QB * 16);
     const int64_t row_b = ld * 2;                  // bytes per token row of qkv
     const unsigned char* base = (const unsigned char*)qkv + (int64_t)b * T * row_b + (int64_t)h * ROWB;
     const int64_t opnd_b = (int64_t)H * ROWB;      // bytes from q to k and from k to v inside a row
     const bool wave_active = q0 < T;               // trailing waves of the last workgroup only help with the fills
 
     bf16x8 qf[QB][KS];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = min(q0 + qb * 16 + r16, T - 1);
-        const unsigned char* qp = base + (int64_t)qrow * row_b;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 * ks + 16 * g));
-    }
-    // this lane's rows of the bias terms
-    const float* hrow[QB];
+    const float* hrow[QB];                         // this lane's rows of the bias terms
     const float* wrow[QB];
+    auto load_queries = [&]() {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int64_t qr = (int64_t)bh * T + min(q0 + qb * 16 + r16, T - 1);
-        hrow[qb] = rel_h + qr * Hk;
-        wrow[qb] = rel_w + qr * Wk;
-    }
+        for (int qb = 0; qb < QB; ++qb) {
+            const int qrow = min(q0 + qb * 16 + r16, T - 1);
+            const unsigned char* qp = base + (int64_t)qrow * row_b;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 * ks + 16 * g));
+            const int64_t qr = (int64_t)bh * T + qrow;
+            hrow[qb] = rel_h + qr * Hk;
+            wrow[qb] = rel_w + qr * Wk;
+        }
+    };
+    load_queries();
 
     auto issue_tile = [&](int t, int buf) {
 #pragma unroll
@@ -93,12 +97,15 @@ __global__ __launch_bounds__(256, 2) void sam_attn_kernel(const __bf16* __restri
 
     f32x4 o[QB][DM + 1];        // un-normalised output, d blocks of 16; [DM]: the running sum of the probabilities
     float mrun[QB];
+    auto reset_state = [&]() {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        mrun[qb] = -INFINITY;
+        for (int qb = 0; qb < QB; ++qb) {
+            mrun[qb] = -INFINITY;
 #pragma unroll
-        for (int m = 0; m <= DM; ++m) o[qb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+            for (int m = 0; m <= DM; ++m) o[qb][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    reset_state();
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -210,6 +217,43 @@ __global__ __launch_bounds__(256, 2) void sam_attn_kernel(const __bf16* __restri
         }
     };
 
+    auto store_queries = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int myq = q0 + qb * 16 + r16;
+            if (myq < T) {
+                const float inv = 1.0f / o[qb][DM][0];
+                __bf16* op = O + ((int64_t)b * T + myq) * ldo + h * HD;
+#pragma unroll
+                for (int m = 0; m < DM; ++m) {
+                    bf16x4 v;
+                    v[0] = (__bf16)(o[qb][m][0] * inv); v[1] = (__bf16)(o[qb][m][1] * inv);
+                    v[2] = (__bf16)(o[qb][m][2] * inv); v[3] = (__bf16)(o[qb][m][3] * inv);
+                    *(bf16x4*)(op + 16 * m + 4 * g) = v;
+                }
+            }
+        }
+    };
+
+    if constexpr (ALLKV) {
+        for (int t = 0; t < nt; ++t) issue_tile(t, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // (q0 of the first pass is this wave's block of workgroup 0: the grid has one workgroup per (image, head))
+        for (; q0 < T; q0 += NW * 16) {
+            if (q0 != wave * 16) { load_queries(); reset_state(); }
+            for (int t = 0; t < nt; ++t) {
+                read_k(t);
+                if (t * KT + KT > T) scores(t, std::true_type{});
+                else scores(t, std::false_type{});
+                read_v(t);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                accumulate(t);
+            }
+            store_queries();
+        }
+        return;
+    }
     issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -231,26 +275,21 @@ __global__ __launch_bounds__(256, 2) void sam_attn_kernel(const __bf16* __restri
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int myq = q0 + qb * 16 + r16;
-        if (myq < T) {
-            const float inv = 1.0f / o[qb][DM][0];
-            __bf16* op = O + ((int64_t)b * T + myq) * ldo + h * HD;
-#pragma unroll
-            for (int m = 0; m < DM; ++m) {
-                bf16x4 v;
-                v[0] = (__bf16)(o[qb][m][0] * inv); v[1] = (__bf16)(o[qb][m][1] * inv);
-                v[2] = (__bf16)(o[qb][m][2] * inv); v[3] = (__bf16)(o[qb][m][3] * inv);
-                *(bf16x4*)(op + 16 * m + 4 * g) = v;
-            }
-        }
-    }
+    store_queries();
 }
 
 template <int HD, int QB>
 int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w, int nb, int T,
            int H, int Hk, int Wk, float c2, hipStream_t s) {
+    if constexpr (HD == 128 && QB == 1) {
+        // every key of a small token grid (the windows) resident in LDS: one workgroup of eight waves per (image, head)
+        if (T <= 4 * KT && T > KT && !(Wk == KT && T == Hk * Wk)) {
+            hipLaunchKernelGGL((sam_attn_kernel<HD, 1, false, 8, true>), dim3(1, nb * H), dim3(512), 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h,
+                               rel_w, T, H, Hk, Wk, c2);
+            MARS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     constexpr int QPB = 4 * QB * 16;
     dim3 grid((T + QPB - 1) / QPB, nb * H), block(256);
     // one key row per tile: no division, and whole 16-byte loads of rel_w (rows of 64 floats are 16-byte aligned)

@@ -364,7 +364,8 @@ def test_generator_small_regions_and_coco_rle(pkg):
 
 
 @pytest.mark.parametrize("nb,gh,gw,H,hd,hdp", [(1, 64, 64, 2, 80, 128), (1, 64, 64, 3, 64, 64), (3, 14, 14, 2, 64, 64),
-                                                  (2, 14, 14, 2, 80, 128), (1, 10, 10, 1, 64, 64), (2, 5, 13, 2, 48, 64)])
+                                                  (2, 14, 14, 2, 80, 128), (1, 10, 10, 1, 64, 64), (2, 5, 13, 2, 48, 64),
+                                                  (3, 16, 16, 2, 80, 128), (1, 9, 9, 1, 96, 128), (2, 8, 8, 1, 80, 128), (1, 13, 5, 3, 80, 128)])
 def test_fused_attention_with_relpos_bias(pkg, nb, gh, gw, H, hd, hdp):
     """marship_sam_attn against softmax(scale q.k + rel_h + rel_w) v in f64 on the same bf16 operands: global
     blocks of a 1024-pixel image (one key row per tile), windows, ragged last tiles, padded head dims."""
