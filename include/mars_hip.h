@@ -350,6 +350,18 @@ int marship_sam_i2t_kv_operands(const void* k, int64_t ldk, const void* v, int64
 int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void* wq, const void* wo, const float* qbias,
                           const float* prm, const void* kv_ops, int Tk, const float* resid, int resid_shared, int prompts,
                           int Ni, float eps, float* y, void* c1, void* stream);
+/* The token -> image attention of a two-way transformer layer at the shipped width (transformer.py:160-166, 192-197, 218-240:
+ * 256 channels, eight heads of 16 dims, at most eight prompt tokens; bf16 operands) with the key and value projections of the
+ * image-side stream made inside the kernel:  k = (x + key_pe) Wk^T + bk, v = x Wv^T + bv, out = softmax(q k^T / 4) v per head.
+ * marship_sam_t2i_q_operands lays the prompts' projected queries q (bf16 [prompts*Tq, ldq]) out as the matrix-instruction
+ * operands the pass reads: q_ops bf16 [prompts][8][64][8].
+ * marship_sam_t2i_block: x bf16 [prompts*Ni, ldx] (the bf16 copy of keys); wk, wv bf16 [32][128][8]: entry (kc, r) = W[r][8kc .. 8kc+7];
+ * kpe_ops bf16 [Ni/32][8][64][8]: key_pe Wk^T in operand order: entry (tile, 2 pair + s, lane (token n, half g))[e] =
+ * (key_pe Wk^T)[32 tile + n][16 (2 pair + s) + 8 (e/4) + 4 g + e%4] (bk may be included or not: a term that is the same for every
+ * image token cancels in the softmax); bv f32 [128]; out bf16 [prompts*Tq, ldo] (columns 0 .. 127).  Ni a multiple of 32. */
+int marship_sam_t2i_q_operands(const void* q, int64_t ldq, int prompts, int Tq, void* q_ops, void* stream);
+int marship_sam_t2i_block(const void* x, int64_t ldx, const void* wk, const void* wv, const void* kpe_ops, const float* bv,
+                          const void* q_ops, int prompts, int Ni, int Tq, void* out, int64_t ldo, void* stream);
 /* masks[b, m, p] = sum_c hyper[b, m, c] * up[b*P + p, c], four masks a prompt, C <= 64 channels (mask_decoder.py:141-143:
  * hyper_in @ upscaled_embedding); hyper f32 [B*4, ldh], up f32 [B*P, ldu], masks f32 [B, 4, P]. */
 int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int64_t ldu, float* masks, int B,

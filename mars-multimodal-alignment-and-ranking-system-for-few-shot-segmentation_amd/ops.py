@@ -783,6 +783,42 @@ def sam_i2t_block(qin: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, qbias: 
                                               stream()), "marship_sam_i2t_block")
 
 
+def sam_t2i_q_operands(q: torch.Tensor, prompts: int, Tq: int, q_ops: torch.Tensor):
+    """The prompts' projected queries q bf16 [prompts*Tq, >= 128] as the operands sam_t2i_block reads: q_ops bf16 [prompts, 8, 64, 8]."""
+    _dev(q, q_ops)
+    _req(q.dtype == q_ops.dtype == torch.bfloat16 and q.dim() == 2 and q.stride(1) == 1 and q.shape[0] >= prompts * Tq and q.shape[1] >= 128,
+         "sam_t2i_q_operands: q")
+    _req(q_ops.is_contiguous() and q_ops.numel() >= prompts * 8 * 64 * 8, "sam_t2i_q_operands: q_ops")
+    hip.check(hip.lib().marship_sam_t2i_q_operands(ptr(q), q.stride(0), prompts, Tq, ptr(q_ops), stream()), "marship_sam_t2i_q_operands")
+
+
+def sam_t2i_kpe_operands(kpe: torch.Tensor) -> torch.Tensor:
+    """key_pe Wk^T (any float dtype, [Ni, 128], Ni a multiple of 32) in the operand order of sam_t2i_block: bf16 [Ni/32, 8, 64, 8]."""
+    Ni = kpe.shape[0]
+    _req(kpe.dim() == 2 and kpe.shape[1] == 128 and Ni % 32 == 0, "sam_t2i_kpe_operands: [Ni, 128], Ni a multiple of 32")
+    lane = torch.arange(64, device=kpe.device)
+    n, g = lane % 32, lane // 32
+    e = torch.arange(8, device=kpe.device)
+    ps = torch.arange(8, device=kpe.device)
+    col = 16 * ps[:, None, None] + 8 * (e[None, None, :] // 4) + 4 * g[None, :, None] + e[None, None, :] % 4          # [8, 64, 8]
+    row = 32 * torch.arange(Ni // 32, device=kpe.device)[:, None, None, None] + n[None, None, :, None]               # [tiles, 1, 64, 1]
+    return kpe[row.expand(-1, 8, -1, 8), col[None].expand(Ni // 32, -1, -1, -1)].to(torch.bfloat16).contiguous()
+
+
+def sam_t2i_block(x: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, kpe_ops: torch.Tensor, bv: torch.Tensor, q_ops: torch.Tensor, prompts: int,
+                  Ni: int, Tq: int, out: torch.Tensor):
+    """Token -> image attention with the key / value projections of the stream made inside the kernel (see marship_sam_t2i_block)."""
+    _dev(x, wk, wv, kpe_ops, bv, q_ops, out)
+    _req(x.dtype == wk.dtype == wv.dtype == kpe_ops.dtype == q_ops.dtype == out.dtype == torch.bfloat16 and bv.dtype == torch.float32, "sam_t2i_block: dtypes")
+    _req(x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= prompts * Ni and x.shape[1] >= 256, "sam_t2i_block: x")
+    _req(wk.is_contiguous() and wk.numel() == 128 * 256 and wv.is_contiguous() and wv.numel() == 128 * 256, "sam_t2i_block: weights")
+    _req(kpe_ops.is_contiguous() and kpe_ops.numel() == Ni // 32 * 8 * 64 * 8 and bv.is_contiguous() and bv.numel() == 128, "sam_t2i_block: kpe_ops / bv")
+    _req(q_ops.is_contiguous() and q_ops.numel() >= prompts * 8 * 64 * 8, "sam_t2i_block: q_ops")
+    _req(out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= prompts * Tq and out.shape[1] >= 128, "sam_t2i_block: out")
+    hip.check(hip.lib().marship_sam_t2i_block(ptr(x), x.stride(0), ptr(wk), ptr(wv), ptr(kpe_ops), ptr(bv), ptr(q_ops), prompts, Ni, Tq, ptr(out),
+                                              out.stride(0), stream()), "marship_sam_t2i_block")
+
+
 def hyper_product(hyper: torch.Tensor, up: torch.Tensor, masks: torch.Tensor, B: int, P: int, C: int):
     """masks[b, m, p] = hyper[b, m, :C] . up[b*P + p, :C]; hyper f32 [B, 4, >= C], up f32 [B*P, >= C], masks f32 [B, 4, P]."""
     _dev(hyper, up, masks)

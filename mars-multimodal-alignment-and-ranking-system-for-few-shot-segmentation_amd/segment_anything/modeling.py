@@ -350,6 +350,11 @@ class _DecAttn:
         if self.small:
             mks = lambda n: Lin(sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"], dtype, device)
             self.qs, self.ks, self.vs, self.os = mks("q_proj"), mks("k_proj"), mks("v_proj"), mks("out_proj")
+            # token -> image attention with the projections of the image stream inside the kernel (ops.sam_t2i_block): the
+            # weights in runs of eight K, run-major
+            if C == 256 and heads == 8 and self.hd == 16 and dtype == torch.bfloat16 and os.environ.get("MARS_SAM_FUSED_T2I", "1") != "0":
+                runs = lambda n: sd[f"{p}.{n}.weight"].float().view(128, 32, 8).permute(1, 0, 2).contiguous().to(device, torch.bfloat16)
+                self.wk_runs, self.wv_runs = runs("k_proj"), runs("v_proj")
             # key and value projections of one input as one product (rows: keys, then values)
             self.kvs = Lin(torch.cat([sd[f"{p}.k_proj.weight"], sd[f"{p}.v_proj.weight"]], 0),
                            torch.cat([sd[f"{p}.k_proj.bias"], sd[f"{p}.v_proj.bias"]], 0), dtype, device)
@@ -463,6 +468,17 @@ class MaskDecoder:
         self._attn.run(q, 0, k, 0, v, 0, o, nb, A.H, Tq, Tk, A.hdp, 1.0 / math.sqrt(A.hd))
         ops.linear(o, A.o.w, out, bias=A.o.b, residual=residual)
 
+    def _t2i_fused(self, A: _DecAttn, kpe_ops: torch.Tensor, tag: str, q_in, x, nb: int, Tq: int, Ni: int, out: torch.Tensor, residual):
+        """Token -> image attention of ``nb`` prompts against their image streams x (bf16 keys, [nb*Ni, C]) with the key and
+        value projections inside the attention kernel; then the output projection (+ residual) as in _attention."""
+        q = self._buf(tag + "qs", (nb * Tq, 128))
+        ops.linear(q_in, A.qs.w, q, bias=A.qs.b)
+        qo = self._buf(tag + "qo", (nb, 8, 64, 8))
+        ops.sam_t2i_q_operands(q, nb, Tq, qo)
+        o = self._buf(tag + "os", (nb * Tq, 128))
+        ops.sam_t2i_block(x, A.wk_runs, A.wv_runs, kpe_ops, A.vs.b, qo, nb, Ni, Tq, o)
+        ops.linear(o, A.os.w, out, bias=A.os.b, residual=residual)
+
     def _pe_terms(self, pe_tokens: torch.Tensor) -> Dict[tuple, torch.Tensor]:
         """key_pe W^T + b for the projections that read keys + key_pe: ("q", i) f32 [Ni, 128] the query projection of layer i's
         image -> token attention; ("k", i) f32 [Ni, 256] the key projection of layer i's token -> image attention (i = number
@@ -480,6 +496,8 @@ class MaskDecoder:
                 t = terms[("k", i)] = torch.empty(pe_tokens.shape[0], 2 * W, dtype=torch.float32, device=self.device)
                 ops.linear(ped, A.ks.w, t[:, :W], bias=A.ks.b)
                 t[:, W:] = A.vs.b
+                if hasattr(A, "wk_runs") and pe_tokens.shape[0] % 32 == 0:
+                    terms[("kops", i)] = ops.sam_t2i_kpe_operands(t[:, :W])
             self._pe_key, self._pe_tab = key, terms
         return self._pe_tab
 
@@ -526,6 +544,9 @@ class MaskDecoder:
         # layer: the positional term enters the projections that would have read it as a table, made once per model.
         fused_i2t = all("i2t_fused" in L and L["t2i"].small for L in self.layers) and self.final.small and Nt <= 8 and Ni % 32 == 0
         pe_terms = self._pe_terms(dense_pe_tokens) if fused_i2t else None
+        # (a workgroup of the fused token -> image kernel serves four prompts: small batches leave the GPU empty and keep the
+        # separate projection and attention launches)
+        fused_t2i = fused_i2t and B >= int(os.environ.get("MARS_SAM_FUSED_T2I_MIN", "256"))
         if not share0:
             ops.stream_copies(Kf, None if fused_i2t else kd, vd, add=None if fused_i2t else dense_pe_tokens)
 
@@ -546,6 +567,8 @@ class MaskDecoder:
             ops.add_cast(Q, pe2, qd)
             if share0 and i == 0:
                 self._attention(L["t2i"], "t2i", qd, kd0, vd0, B, Nt, Ni, Q, Q, kv_shared=True)
+            elif fused_i2t and fused_t2i and ("kops", i) in pe_terms:
+                self._t2i_fused(L["t2i"], pe_terms[("kops", i)], "t2i", qd, vd, B, Nt, Ni, Q, Q)
             elif fused_i2t:
                 self._attention(L["t2i"], "t2i", qd, vd, vd, B, Nt, Ni, Q, Q, k_pe=pe_terms[("k", i)])
             else:
@@ -578,7 +601,9 @@ class MaskDecoder:
             ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens, norm=L["n4"], eps=1e-5,
                               write_back=i + 1 < len(self.layers))        # (nothing reads the f32 stream after the last layer)
         ops.add_cast(Q, pe2, qd)
-        if fused_i2t:
+        if fused_i2t and fused_t2i and ("kops", len(self.layers)) in pe_terms:
+            self._t2i_fused(self.final, pe_terms[("kops", len(self.layers))], "fin", qd, vd, B, Nt, Ni, Q, Q)
+        elif fused_i2t:
             self._attention(self.final, "fin", qd, vd, vd, B, Nt, Ni, Q, Q, k_pe=pe_terms[("k", len(self.layers))])
         else:
             self._attention(self.final, "fin", qd, kd, vd, B, Nt, Ni, Q, Q)

@@ -1181,3 +1181,28 @@ def test_sam_i2t_block_matches_torch(pkg, cuda, prompts, Ni, Tk, shared, write_y
         assert float((y.double() - ref).abs().max()) <= 2e-2
         assert torch.equal(c1, y.to(bf))                          # the copy is the rounding of what was written
     assert float((c1.double() - ref).abs().max()) <= 5e-2
+
+
+@pytest.mark.parametrize("prompts,Ni,Tq", [(5, 256, 7), (2, 4096, 7), (9, 64, 8), (3, 32, 1), (4, 96, 5)])
+def test_sam_t2i_block_matches_torch(pkg, cuda, prompts, Ni, Tq):
+    """Token -> image attention with the key / value projections of the stream inside the kernel, against the separate steps
+    in f64 on the same bf16 operands (k, v and the probabilities are rounded to bf16 inside the kernel)."""
+    bf = torch.bfloat16
+    x = _rand((prompts * Ni, 256), 61, cuda).to(bf)
+    pe = _rand((Ni, 256), 62, cuda)
+    wk, bk = (_rand((128, 256), 63, cuda) * 0.06).to(bf), _rand((128,), 64, cuda)
+    wv, bv = (_rand((128, 256), 65, cuda) * 0.06).to(bf), _rand((128,), 66, cuda) * 0.3
+    q = (_rand((prompts * Tq, 128), 67, cuda) * 1.5).to(bf)
+    runs = lambda w: w.view(128, 32, 8).permute(1, 0, 2).contiguous()
+    kpe = pe.to(bf).double() @ wk.double().t() + bk.double()                # (with the bias: it cancels)
+    kpe_ops = pkg.ops.sam_t2i_kpe_operands(kpe.float())
+    q_ops = torch.empty(prompts, 8, 64, 8, device=cuda, dtype=bf)
+    pkg.ops.sam_t2i_q_operands(q, prompts, Tq, q_ops)
+    out = torch.full((prompts * Tq, 128), float("nan"), device=cuda, dtype=bf)
+    pkg.ops.sam_t2i_block(x, runs(wk), runs(wv), kpe_ops, bv, q_ops, prompts, Ni, Tq, out)
+    k = (x.double() @ wk.double().t()).view(prompts, Ni, 8, 16) + kpe.to(bf).double().view(1, Ni, 8, 16)
+    v = (x.double() @ wv.double().t() + bv.double()).view(prompts, Ni, 8, 16)
+    qh = q.double().view(prompts, Tq, 8, 16)
+    s = torch.einsum("bqhd,bnhd->bhqn", qh, k) * 0.25
+    ref = torch.einsum("bhqn,bnhd->bqhd", torch.softmax(s, -1), v).reshape(prompts * Tq, 128)
+    assert float((out.double() - ref).abs().max()) <= 3e-2                   # |v| ~ 1: roundings of k, p, v to bf16 and of the result

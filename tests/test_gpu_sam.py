@@ -522,3 +522,34 @@ def test_fused_image_to_token_block_agrees_with_separate_launches(pkg, monkeypat
     assert float((i1 - i0).abs().max()) <= 2e-2
     assert float((l1 - l0).abs().max()) <= 3e-2 * scale
     assert float(((m1 > 0) != (m0 > 0)).float().mean()) < 5e-3
+
+
+def test_fused_token_to_image_block_agrees_with_separate_launches(pkg, monkeypatch):
+    """bf16 decoder at the shipped width: token -> image attention with the key / value projections inside the kernel against
+    projection + attention launches (the switch that sends small batches to the separate launches is lowered for the test)."""
+    sa = pkg.segment_anything
+    sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["geom"], seed=3)
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8)
+    pts = np.stack([rng.uniform(0, 400, 9), rng.uniform(0, 300, 9)], -1)[:, None, :]
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MARS_SAM_FUSED_T2I", flag)
+        monkeypatch.setenv("MARS_SAM_FUSED_T2I_MIN", "1")
+        sam = sa.sam_model_registry["geom"](state_dict=sd, device="cuda", dtype=torch.bfloat16)
+        assert hasattr(sam.mask_decoder.final, "wk_runs") == (flag == "1")
+        calls = []
+        orig = pkg.ops.sam_t2i_block
+        monkeypatch.setattr(pkg.ops, "sam_t2i_block", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        pred = sa.SamPredictor(sam)
+        pred.set_image(img)
+        coords = torch.as_tensor(pred.transform.apply_coords(pts, img.shape[:2]), dtype=torch.float32, device="cuda")
+        masks, iou, low = pred.predict_torch(coords, torch.ones(9, 1, dtype=torch.int32, device="cuda"), multimask_output=True, return_logits=True)
+        monkeypatch.setattr(pkg.ops, "sam_t2i_block", orig)
+        assert len(calls) == (len(sam.mask_decoder.layers) if flag == "1" else 0)      # every layer after the first, and the final attention
+        res.append((masks.float().clone(), iou.float().clone(), low.float().clone()))
+    (m1, i1, l1), (m0, i0, l0) = res
+    scale = float(l0.abs().max())
+    assert float((i1 - i0).abs().max()) <= 2e-2
+    assert float((l1 - l0).abs().max()) <= 3e-2 * scale
+    assert float(((m1 > 0) != (m0 > 0)).float().mean()) < 5e-3
