@@ -519,7 +519,7 @@ class MaskDecoder:
         Q = self._buf("Q", (B * Nt, C), f32); Q.copy_(tokens.view(B * Nt, C))
         # src = image embedding + dense prompt embedding, one copy per prompt (:126-127)
         Kf = self._buf("K", (B * Ni, C), f32)
-        qd, kd, vd = self._buf("qd", (B * Nt, C)), self._buf("kd", (B * Ni, C)), self._buf("vd", (B * Ni, C))
+        qd, vd = self._buf("qd", (B * Nt, C)), self._buf("vd", (B * Ni, C))
         # Without mask prompts the image stream entering the first layer is the same for every prompt: its key, value and
         # query projections are made once, and the stream only becomes per-prompt when the first layer's image -> token
         # attention writes it.
@@ -547,6 +547,7 @@ class MaskDecoder:
         # (a workgroup of the fused token -> image kernel serves four prompts: small batches leave the GPU empty and keep the
         # separate projection and attention launches)
         fused_t2i = fused_i2t and B >= int(os.environ.get("MARS_SAM_FUSED_T2I_MIN", "256"))
+        kd = None if fused_i2t else self._buf("kd", (B * Ni, C))          # (keys + key_pe: only the separate launches read it)
         if not share0:
             ops.stream_copies(Kf, None if fused_i2t else kd, vd, add=None if fused_i2t else dense_pe_tokens)
 
