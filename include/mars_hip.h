@@ -290,7 +290,7 @@ int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd
 /* The attention of an encoder block in one kernel, without the score matrix (image_encoder.py:224-240 with the
  * bias of :357-359): O[b*T+t, head*hdp+d] = sum_k softmax_k(scale q.k + rel_h[.., k / Wk] + rel_w[.., k % Wk]) v[k, d]
  * for bf16 qkv rows (row stride ld; q, k, v of head h at columns h*hdp, (H+h)*hdp, (2H+h)*hdp), hdp 64 or 128
- * (zero-padded head dims give zero outputs), rel_h [nb*H, T, Hk], rel_w [nb*H, T, Wk] as marship_relpos_bias
+ * (zero-padded head dims give zero outputs) or 80 (the ViT-H head as it is), rel_h [nb*H, T, Hk], rel_w [nb*H, T, Wk] as marship_relpos_bias
  * leaves them.  Replaces the score product, marship_softmax_bias_rows and the P.V product for bf16 towers. */
 int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
                      int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream);

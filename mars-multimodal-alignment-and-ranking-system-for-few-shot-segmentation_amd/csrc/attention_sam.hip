@@ -38,7 +38,9 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 a, f32x4 b) {
     return r;
 }
 
-// HD: padded head dim (64 or 128); QB: 16-query blocks per wave; four waves per workgroup.  K / V tiles of 64 keys
+// HD: head dim as stored (64 or 128: padded; 80: the ViT-H head as it is, 160-byte rows - the matrix instruction's third
+// K step is half zeros in registers, and the LDS rows are laid out linearly without the bank swizzle, which needs a
+// power-of-two row); QB: 16-query blocks per wave; four waves per workgroup.  K / V tiles of 64 keys
 // are double buffered and filled by LDS-DMA; a tile's last fragments are in registers before the fill of the next
 // tile starts (hipcc would otherwise drain the DMAs in front of every LDS read that follows one).
 // ALLKV (T <= 4 tiles: the 14 x 14 windows): one workgroup of NW waves per (image, head); all of K and V is brought into
@@ -50,11 +52,12 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
                                                           int64_t ldo, const float* __restrict__ rel_h,
                                                           const float* __restrict__ rel_w, int T, int H, int Hk, int Wk,
                                                           float c2) {
-    constexpr int ROWB = HD * 2, KS = HD / 32, DM = HD / 16, QPB = NW * QB * 16;
+    constexpr int ROWB = HD * 2, KS = (HD + 31) / 32, DM = HD / 16, QPB = NW * QB * 16;
+    constexpr bool LINEAR = (1024 % ROWB) != 0;    // rows that do not tile a 1-KiB fill piece: no swizzle
     static_assert(!ALLKV || QB == 1, "the resident form walks one 16-query block a wave at a time");
     constexpr int PPO = KT * ROWB / 1024;          // 1-KiB DMA pieces per operand tile
-    constexpr int PPW = 2 * PPO / NW;              // pieces per wave and tile
-    constexpr int RPP = 1024 / ROWB, LPR = ROWB / 16;     // key rows per piece, lanes per key row
+    constexpr int LPR = ROWB / 16;                 // 16-byte chunks (lanes of a fill) per key row
+    static_assert(KT * ROWB % 1024 == 0, "an operand tile is a whole number of fill pieces");
     __shared__ __attribute__((aligned(16))) unsigned char lds[ALLKV ? 4 : 2][2][KT * ROWB];      // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,7 +78,10 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
             const int qrow = min(q0 + qb * 16 + r16, T - 1);
             const unsigned char* qp = base + (int64_t)qrow * row_b;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 * ks + 16 * g));
+            for (int ks = 0; ks < KS; ++ks) {
+                qf[qb][ks] = bf16x8{};
+                if (4 * ks + g < LPR) qf[qb][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(qp + 64 * ks + 16 * g));
+            }
             const int64_t qr = (int64_t)bh * T + qrow;
             hrow[qb] = rel_h + qr * Hk;
             wrow[qb] = rel_w + qr * Wk;
@@ -85,10 +91,10 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
 
     auto issue_tile = [&](int t, int buf) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = wave * PPW + i, opnd = p / PPO, pp = p % PPO;
-            const int row = RPP * pp + lane / LPR, slot = lane % LPR;
-            const int chunk = slot ^ ((row >> 1) & 7);
+        for (int p = wave; p < 2 * PPO; p += NW) {       // fill pieces of 1 KiB: 64 consecutive chunks of an operand tile
+            const int opnd = p / PPO, pp = p % PPO;
+            const int c = pp * 64 + lane, row = c / LPR, slot = c - row * LPR;
+            const int chunk = LINEAR ? slot : slot ^ ((row >> 1) & 7);
             const int key = min(t * KT + row, T - 1);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (1 + opnd) * opnd_b + (int64_t)key * row_b + chunk * 16),
                                              (lds_ptr_t)(&lds[buf][opnd][pp * 1024]), 16, 0, 0);
@@ -121,14 +127,18 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
         for (int f = 0; f < 4; ++f)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                kf[f][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt + (16 * f + r16) * ROWB + (((4 * ks + g) ^ ksw) << 4)));
+            {
+                kf[f][ks] = bf16x8{};
+                if (4 * ks + g < LPR)
+                    kf[f][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt + (16 * f + r16) * ROWB + ((LINEAR ? 4 * ks + g : (4 * ks + g) ^ ksw) << 4)));
+            }
     };
     auto read_v = [&](int buf) {
         const unsigned char* vt = &lds[buf][1][0];
 #pragma unroll
         for (int m = 0; m < DM; ++m) {
             // V^T[d = 16 m + 4 vp ..][keys]: byte column 32 m + 8 vp of rows 32 s + 4 g + vq and + 16
-            const int off = (4 * g + vq) * ROWB + (((2 * m + (vp >> 1)) ^ vsw) << 4) + 8 * (vp & 1);
+            const int off = (4 * g + vq) * ROWB + ((LINEAR ? 2 * m + (vp >> 1) : (2 * m + (vp >> 1)) ^ vsw) << 4) + 8 * (vp & 1);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vt + off + s * 32 * ROWB));
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
 template <int HD, int QB>
 int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w, int nb, int T,
            int H, int Hk, int Wk, float c2, hipStream_t s) {
-    if constexpr (HD == 128 && QB == 1) {
+    if constexpr (QB == 1) {
         // every key of a small token grid (the windows) resident in LDS: one workgroup of eight waves per (image, head)
         if (T <= 4 * KT && T > KT && !(Wk == KT && T == Hk * Wk)) {
             hipLaunchKernelGGL((sam_attn_kernel<HD, 1, false, 8, true>), dim3(1, nb * H), dim3(512), 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h,
@@ -307,11 +317,12 @@ extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ld
                                 int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream) {
     MARS_CHECK(qkv && O && rel_h && rel_w, "sam_attn: null pointer");
     MARS_CHECK(nb > 0 && T > 0 && H > 0 && Hk > 0 && Wk > 0 && Hk * Wk >= T, "sam_attn: bad shape nb=%d T=%d H=%d Hk=%d Wk=%d", nb, T, H, Hk, Wk);
-    MARS_CHECK(hdp == 64 || hdp == 128, "sam_attn: padded head dim %d (64 or 128)", hdp);
+    MARS_CHECK(hdp == 64 || hdp == 80 || hdp == 128, "sam_attn: head dim as stored %d (64, 80 or 128)", hdp);
     MARS_CHECK(ld >= 3 * (int64_t)H * hdp && ld % 8 == 0 && ldo >= (int64_t)H * hdp && ldo % 4 == 0, "sam_attn: row strides");
     MARS_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)O % 8) == 0, "sam_attn: alignment");
     MARS_CHECK((int64_t)nb * H <= 65535, "sam_attn: too many (image, head) pairs for one launch");
     const float c2 = scale * 1.4426950408889634f;
     if (hdp == 64) return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+    if (hdp == 80) return launch<80, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
     return launch<128, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
 }

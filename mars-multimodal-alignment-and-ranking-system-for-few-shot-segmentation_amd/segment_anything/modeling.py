@@ -118,7 +118,12 @@ class ImageEncoderViT:
         assert D % 64 == 0 and cfg.out_chans % 64 == 0, "widths must be multiples of 64 (GEMM K granularity)"
         self.G = G = cfg.img_size // cfg.patch_size
         self.hd = hd = D // H
-        self.hdp = hdp = _pad_to(hd, 64)
+        # bf16 towers: scores, bias, softmax and P.V in one kernel (no [heads, T, T] score matrix); MARS_FLASH=0 or
+        # an f32 tower keep the three-launch form, whose products need head dims padded to a multiple of 64.  The fused
+        # kernel also takes the 80-dim heads of ViT-H as they are (MARS_SAM_HEAD80=0: padded to 128 like the rest): the
+        # qkv product and the projection lose the 37 % of their columns / K that were zeros.
+        fused_ok = dtype == torch.bfloat16 and os.environ.get("MARS_FLASH", "1") != "0"
+        self.hdp = hdp = 80 if (hd == 80 and fused_ok and os.environ.get("MARS_SAM_HEAD80", "1") != "0") else _pad_to(hd, 64)
         dev = self.device
         self.patch = Lin(sd[prefix + ".patch_embed.proj.weight"].reshape(D, -1), sd[prefix + ".patch_embed.proj.bias"], dtype, dev)
         self.pos = _dev_f32(sd[prefix + ".pos_embed"].reshape(G * G, D), dev)
@@ -146,9 +151,7 @@ class ImageEncoderViT:
         self.neck2 = Lin(sd[prefix + ".neck.2.weight"].permute(0, 2, 3, 1).reshape(C, 9 * C), None, dtype, dev)
         self.neck3 = (_dev_f32(sd[prefix + ".neck.3.weight"], dev), _dev_f32(sd[prefix + ".neck.3.bias"], dev))
         self._attn = _Attn(dev, dtype)
-        # bf16 towers: scores, bias, softmax and P.V in one kernel (no [heads, T, T] score matrix); MARS_FLASH=0 or
-        # an f32 tower keep the three-launch form
-        self.fused_attention = dtype == torch.bfloat16 and hdp in (64, 128) and os.environ.get("MARS_FLASH", "1") != "0"
+        self.fused_attention = fused_ok and hdp in (64, 80, 128)
         self._build_index_maps()
         self._mean = torch.tensor(PIXEL_MEAN, dtype=torch.float32, device=dev)
         self._std = torch.tensor(PIXEL_STD, dtype=torch.float32, device=dev)
@@ -215,6 +218,9 @@ class ImageEncoderViT:
             if self.fused_attention:
                 ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5)
             else:
+                if hdp % 64:
+                    raise RuntimeError("this tower stores its heads unpadded for the fused attention kernel; build it with MARS_FLASH=0 "
+                                       "(or MARS_SAM_HEAD80=0) to run the three-launch form")
                 self._attn.run(qkv, 0, qkv, H * hdp, qkv, 2 * H * hdp, ao, nb, H, Tt, Tt, hdp, hd ** -0.5, rel=(rel_h, rel_w, Tt // gw, gw))
             if b.ws > 0:
                 ops.gather_rows(ao, self.unpart_idx, w["aou"])

@@ -365,7 +365,9 @@ def test_generator_small_regions_and_coco_rle(pkg):
 
 @pytest.mark.parametrize("nb,gh,gw,H,hd,hdp", [(1, 64, 64, 2, 80, 128), (1, 64, 64, 3, 64, 64), (3, 14, 14, 2, 64, 64),
                                                   (2, 14, 14, 2, 80, 128), (1, 10, 10, 1, 64, 64), (2, 5, 13, 2, 48, 64),
-                                                  (3, 16, 16, 2, 80, 128), (1, 9, 9, 1, 96, 128), (2, 8, 8, 1, 80, 128), (1, 13, 5, 3, 80, 128)])
+                                                  (3, 16, 16, 2, 80, 128), (1, 9, 9, 1, 96, 128), (2, 8, 8, 1, 80, 128), (1, 13, 5, 3, 80, 128),
+                                                  (1, 64, 64, 2, 80, 80), (2, 14, 14, 3, 80, 80), (3, 16, 16, 2, 80, 80), (1, 9, 9, 1, 80, 80),
+                                                  (2, 8, 8, 1, 80, 80), (1, 13, 5, 3, 80, 80), (1, 20, 20, 2, 80, 80)])
 def test_fused_attention_with_relpos_bias(pkg, nb, gh, gw, H, hd, hdp):
     """marship_sam_attn against softmax(scale q.k + rel_h + rel_w) v in f64 on the same bf16 operands: global
     blocks of a 1024-pixel image (one key row per tile), windows, ragged last tiles, padded head dims."""
@@ -395,7 +397,7 @@ def test_fused_attention_with_relpos_bias(pkg, nb, gh, gw, H, hd, hdp):
 
 
 @pytest.mark.parametrize("arch", ["tiny", "tiny80"])
-def test_encoder_fused_attention_agrees_with_three_launch_form(pkg, arch):
+def test_encoder_fused_attention_agrees_with_three_launch_form(pkg, arch, monkeypatch):
     """bf16 encoder with the fused attention against the same encoder with scores, softmax and P.V as three
     launches: both are one bf16 rounding per operand away from the f32 encoder."""
     sa = pkg.segment_anything
@@ -405,9 +407,10 @@ def test_encoder_fused_attention_agrees_with_three_launch_form(pkg, arch):
     ref = torch.as_tensor(GOLD[f"sam_{arch}_features"]).cuda()
     feats = {}
     for fused in (True, False):
+        monkeypatch.setenv("MARS_FLASH", "1" if fused else "0")       # (80-dim heads are stored unpadded for the fused kernel only)
         sam = sa.sam_model_registry[arch](state_dict=sd, device="cuda", dtype=torch.bfloat16)
-        assert sam.image_encoder.fused_attention
-        sam.image_encoder.fused_attention = fused
+        assert sam.image_encoder.fused_attention == fused
+        assert sam.image_encoder.hdp == ((80 if fused else 128) if arch == "tiny80" else 64)
         pred = sa.SamPredictor(sam)
         pred.set_image(img)
         feats[fused] = pred.features.float().clone()

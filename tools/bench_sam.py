@@ -42,7 +42,7 @@ def main():
     pred = sa.SamPredictor(sam)
     print(f"set_image: {timed(lambda: pred.set_image(img), a.reps):.2f} ms", flush=True)
     enc = sam.image_encoder
-    if getattr(enc, "fused_attention", False):
+    if getattr(enc, "fused_attention", False) and enc.hdp % 64 == 0:
         enc.fused_attention = False
         print(f"set_image with scores / softmax / P.V as three launches: {timed(lambda: pred.set_image(img), a.reps):.2f} ms "
               f"(workspace {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB)", flush=True)
