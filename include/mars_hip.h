@@ -379,11 +379,12 @@ typedef struct MarsAxisTable { const int32_t* lo; const int32_t* size; const flo
  * with ty [H entries], the order and sums of marship_resample_axis) and never stored.  Plane p of the input starts at
  * low + (p / nm) * stride_b + (p % nm) * stride_c.  max_rows = the most source rows any band reads (the caller computes it
  * from ty; max_rows * (L + W) floats must fit in 64 KB of LDS).
- * marship_resample_mask_stats: stats[p] of marship_mask_stats for planes 0 .. n-1.
+ * marship_resample_mask_stats: stats[p] of marship_mask_stats for planes 0 .. n-1; with `bits` (f32 [n, H, W], may be NULL) also
+ *   what marship_resample_threshold writes for every plane, in the same pass (for callers whose filters keep every mask).
  * marship_resample_threshold: out[i] f32 [H, W] = (logits of plane sel[i] (or i when sel is NULL) > thr) as 0 / 1. */
 int marship_resample_mask_stats(const float* low, int64_t stride_b, int64_t stride_c, int nm, int n, int L, int H, int W,
                                 const MarsAxisTable* tx, const MarsAxisTable* ty, int band, int max_rows, float thr,
-                                float off, int32_t* stats, void* stream);
+                                float off, int32_t* stats, float* bits, void* stream);
 int marship_resample_threshold(const float* low, int64_t stride_b, int64_t stride_c, int nm, const int32_t* sel, int nsel,
                                int L, int H, int W, const MarsAxisTable* tx, const MarsAxisTable* ty, int band,
                                int max_rows, float thr, float* out, void* stream);

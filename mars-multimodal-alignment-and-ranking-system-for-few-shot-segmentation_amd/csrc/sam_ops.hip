@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void resample_bands_kernel(const float* __rest
                     hi += acc > thr + off;
                     lo += acc > thr - off;
                     if (acc > thr) { x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y); }
+                    if (out) out[((int64_t)slot * H + y) * W + x] = acc > thr ? 1.f : 0.f;       // (callers that keep every mask)
                 } else {
                     out[((int64_t)slot * H + y) * W + x] = acc > thr ? 1.f : 0.f;
                 }
@@ -585,7 +586,7 @@ int check_bands(const char* what, const float* low, int nm, int L, int H, int W,
 
 extern "C" int marship_resample_mask_stats(const float* low, int64_t stride_b, int64_t stride_c, int nm, int n, int L, int H, int W,
                                            const MarsAxisTable* tx, const MarsAxisTable* ty, int band, int max_rows, float thr, float off,
-                                           int32_t* stats, void* stream) {
+                                           int32_t* stats, float* bits, void* stream) {
     if (check_bands("resample_mask_stats", low, nm, L, H, W, tx, ty, band, max_rows)) return -1;
     MARS_CHECK(stats && n > 0, "resample_mask_stats: bad arguments");
     const AxisTable ax = {tx->lo, tx->size, tx->w, tx->kmax}, ay = {ty->lo, ty->size, ty->w, ty->kmax};
@@ -593,7 +594,7 @@ extern "C" int marship_resample_mask_stats(const float* low, int64_t stride_b, i
     const int kt = ax.kmax <= 4 && ay.kmax <= 4 ? 4 : ax.kmax <= 8 && ay.kmax <= 8 ? 8 : 0;
 #define MARS_BANDS(KT)                                                                                                                       \
     hipLaunchKernelGGL((resample_bands_kernel<true, KT>), dim3((unsigned)n), dim3(256), shm, (hipStream_t)stream, low, stride_b, stride_c, nm,    \
-                       (const int32_t*)nullptr, L, H, W, ax, ay, band, max_rows, thr, off, stats, (float*)nullptr)
+                       (const int32_t*)nullptr, L, H, W, ax, ay, band, max_rows, thr, off, stats, bits)
     if (kt == 4) MARS_BANDS(4); else if (kt == 8) MARS_BANDS(8); else MARS_BANDS(0);
 #undef MARS_BANDS
     MARS_LAUNCH_CHECK();

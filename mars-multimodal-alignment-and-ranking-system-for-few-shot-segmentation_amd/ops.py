@@ -860,16 +860,20 @@ def _low_planes(low: torch.Tensor):
     return B, nm, L
 
 
-def resample_mask_stats(low: torch.Tensor, tx, ty, band: int, max_rows: int, thr: float, off: float, out: torch.Tensor):
+def resample_mask_stats(low: torch.Tensor, tx, ty, band: int, max_rows: int, thr: float, off: float, out: torch.Tensor,
+                        bits: Optional[torch.Tensor] = None):
     """mask_stats of the image-size logits that (tx, ty) make from ``low`` [B, nm, L, L] (a view is fine), without storing them:
-    out i32 [B*nm, 6].  (band, max_rows) from resample.band_plan on the host copy of ty."""
+    out i32 [B*nm, 6].  (band, max_rows) from resample.band_plan on the host copy of ty.  ``bits`` f32 [B*nm, H, W]: also the
+    0 / 1 masks of every plane, in the same pass."""
     B, nm, L = _low_planes(low)
-    _dev(low, out)
+    _dev(low, out, bits)
     _req(out.dtype == torch.int32 and out.is_contiguous() and out.numel() >= 6 * B * nm, "resample_mask_stats: out")
+    _req(bits is None or (bits.dtype == torch.float32 and bits.is_contiguous() and bits.numel() >= B * nm * ty[0].numel() * tx[0].numel()),
+         "resample_mask_stats: bits")
     ax, ay = _axis_table(tx), _axis_table(ty)
     hip.check(hip.lib().marship_resample_mask_stats(ptr(low), low.stride(0), low.stride(1), nm, B * nm, L, ty[0].numel(), tx[0].numel(),
-                                                    ctypes.byref(ax), ctypes.byref(ay), band, max_rows, float(thr), float(off), ptr(out), stream()),
-              "marship_resample_mask_stats")
+                                                    ctypes.byref(ax), ctypes.byref(ay), band, max_rows, float(thr), float(off), ptr(out), ptr(bits),
+                                                    stream()), "marship_resample_mask_stats")
 
 
 def resample_threshold(low: torch.Tensor, sel: Optional[torch.Tensor], tx, ty, band: int, max_rows: int, thr: float, out: torch.Tensor):

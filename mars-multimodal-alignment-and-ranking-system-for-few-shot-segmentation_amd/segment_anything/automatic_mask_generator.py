@@ -90,10 +90,12 @@ class SamAutomaticMaskGenerator:
         nm, n = low.shape[1], low.shape[0] * low.shape[1]
         iou = iou.flatten(0, 1)
         stats = torch.empty(n, 6, dtype=torch.int32, device=dev)
-        plan = None
+        plan, all_bits = None, None
         if masks is None:                                             # logits evaluated from ``low`` inside the kernels
             plan = pr.model.postprocess_plan(low.shape[-1], pr.input_size, pr.original_size)
-            ops.resample_mask_stats(low, *plan, pr.model.mask_threshold, stab_off, stats)
+            if iou_thresh <= 0.0 and stab_thresh <= 0.0:             # no filter: every mask is kept, its 0 / 1 form comes out of the same pass
+                all_bits = torch.empty(n, int(pr.original_size[0]), int(pr.original_size[1]), dtype=torch.float32, device=dev)
+            ops.resample_mask_stats(low, *plan, pr.model.mask_threshold, stab_off, stats, bits=all_bits)
         else:
             masks = masks.flatten(0, 1).contiguous()
             ops.mask_stats(masks, pr.model.mask_threshold, stab_off, stats)
@@ -108,7 +110,10 @@ class SamAutomaticMaskGenerator:
         if idx.numel() == 0:
             return
         sel = idx.to(dev)
-        if masks is None:
+        if all_bits is not None:
+            binm = all_bits
+            low_kept = low.clone(memory_format=torch.contiguous_format).view(n, low.shape[-2], low.shape[-1])      # (low is a view of a reused buffer)
+        elif masks is None:
             oh, ow = pr.original_size
             binm = torch.empty(idx.numel(), int(oh), int(ow), dtype=torch.float32, device=dev)
             ops.resample_threshold(low, idx.to(torch.int32).to(dev), *plan, pr.model.mask_threshold, binm)

@@ -470,6 +470,9 @@ def test_on_the_fly_postprocess_equals_the_stored_form(pkg, L, S, inp, orig):
     got = torch.full_like(want, -7)
     ops.resample_mask_stats(low, tw, th, band, rows, 0.0, 1.0, got)
     assert torch.equal(got, want)
+    got2, bits_all = torch.full_like(want, -7), torch.full((B * nm, oh, ow), 9.0, device=dev)
+    ops.resample_mask_stats(low, tw, th, band, rows, 0.0, 1.0, got2, bits=bits_all)          # statistics and masks in one pass
+    assert torch.equal(got2, want) and torch.equal(bits_all, (full > 0.0).float())
     assert int(want[4, 0]) == 0 and want[4, 2:].tolist() == [0, 0, 0, 0]   # (plane 4 = prompt 1, mask 2 of the view)
     sel = torch.tensor([7, 0, 14, 4, 3], dtype=torch.int32, device=dev)
     bits = torch.full((5, oh, ow), 9.0, device=dev)
