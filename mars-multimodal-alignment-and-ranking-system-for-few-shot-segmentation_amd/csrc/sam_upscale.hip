@@ -25,25 +25,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-// 0.5 v (1 + erf(v / sqrt 2)), erf by Abramowitz & Stegun 7.1.26 (absolute error below 1.5e-7, i.e. f32 rounding
-// level for the activations here): erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z >= 0.
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float a = fabsf(v), z = a * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = p * t * __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
-    return fmaf(-0.5f * a, e, fmaxf(v, 0.f));          // v >= 0: v - v e / 2;  v < 0: -|v| e / 2
-}
-
 // (sum over both half-waves of a, in the lower half-wave; of b, in the upper)
 __device__ __forceinline__ float halves_sum2(float a, float b) {
     const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 __device__ __forceinline__ float halves_sum(float a) { return halves_sum2(a, a); }
+
+// 0.5 v (1 + erf(v / sqrt 2)), erf by Abramowitz & Stegun 7.1.26 (absolute error below 1.5e-7, i.e. f32 rounding
+// level for the activations here): erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z >= 0; the result
+// is v - v e / 2 for v >= 0 and -|v| e / 2 below.  Two values at a time: the multiplies and multiply-adds are
+// v_pk_*_f32 (two values an issue slot); only the reciprocal and the exponential stay one value an instruction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    const f32x2 a = __builtin_elementwise_abs(v), z = a * 0.70710678118654752440f;
+    const f32x2 d = z * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = t * 1.061405429f + -1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t + -0.284496736f;
+    p = p * t + 0.254829592f;
+    const f32x2 x = z * z * -1.44269504088896340736f;
+    const f32x2 ex = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+    const f32x2 e = p * t * ex;
+    return (a * -0.5f) * e + __builtin_elementwise_max(v, (f32x2)(0.f));
+}
 
 constexpr int UP0_K = 256, UP0_C = 64;          // first transposed convolution: channels in, channels out
 constexpr int UP0_LDS_W = 4 * UP0_C * UP0_K * 2; // bytes of its weight as bf16
@@ -119,10 +125,11 @@ __global__ __launch_bounds__(512) void upscale_ln_gelu_kernel(const __bf16* __re
                         const f32x4 lw = *(const f32x4*)(sP + UP0_C + mb * 32 + i * 8 + half * 4);
                         const f32x4 lb = *(const f32x4*)(sP + 2 * UP0_C + mb * 32 + i * 8 + half * 4);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float r = gelu_erf(fmaf(acc[mb][4 * i + j] * rstd, lw[j], lb[j]));
-                            if (u == 0) g0[j] = (__bf16)r;
-                            else g1[j] = (__bf16)r;
+                        for (int j = 0; j < 4; j += 2) {
+                            const f32x2 r = gelu_erf2((f32x2){acc[mb][4 * i + j], acc[mb][4 * i + j + 1]} * rstd * (f32x2){lw[j], lw[j + 1]} +
+                                                      (f32x2){lb[j], lb[j + 1]});
+                            if (u == 0) { g0[j] = (__bf16)r[0]; g0[j + 1] = (__bf16)r[1]; }
+                            else { g1[j] = (__bf16)r[0]; g1[j + 1] = (__bf16)r[1]; }
                         }
                     }
                     const v2i32 ai = __builtin_bit_cast(v2i32, g0), bi = __builtin_bit_cast(v2i32, g1);
@@ -175,17 +182,17 @@ __global__ __launch_bounds__(256) void upscale_masks_kernel(const __bf16* __rest
             f32x16 acc = (f32x16)(0.f);
 #pragma unroll
             for (int ks = 0; ks < UP3_K / 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[pos][ks], xb[ks], acc, 0, 0, 0);
-            float part[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x2 part[4] = {(f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f)};      // (even, odd channels: summed at the end)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float g = gelu_erf(acc[4 * i + j] + cb[i][j]);
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 g = gelu_erf2((f32x2){acc[4 * i + j] + cb[i][j], acc[4 * i + j + 1] + cb[i][j + 1]});
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) part[m] = fmaf(g, hy[m][i][j], part[m]);
+                    for (int m = 0; m < 4; ++m) part[m] = g * (f32x2){hy[m][i][j], hy[m][i][j + 1]} + part[m];
                 }
-            val[pos][0] = halves_sum2(part[0], part[2]);      // lower half-wave: mask 0, upper: mask 2
-            val[pos][1] = halves_sum2(part[1], part[3]);      //                       1           3
+            val[pos][0] = halves_sum2(part[0][0] + part[0][1], part[2][0] + part[2][1]);      // lower half-wave: mask 0, upper: mask 2
+            val[pos][1] = halves_sum2(part[1][0] + part[1][1], part[3][0] + part[3][1]);      //                       1           3
         }
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
