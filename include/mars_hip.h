@@ -330,7 +330,7 @@ int marship_layernorm_act_rows(const float* x, const float* w, const float* b, f
  *   (G2 = 2G, a multiple of 32); w3 bf16 [(dy, dx, c) = 128][64]; bias f32 [32]; hyper f32 [prompts*4, ldh]; masks f32
  *   [prompts, 4, 2*G2, 2*G2].  GELU in both is the erf form evaluated to 1.5e-7 absolute. */
 int marship_sam_upscale_ln_gelu(const void* x, int64_t ldx, const void* w0, const float* prm, float eps, void* out,
-                                int64_t ldo, int64_t prompts, int G, void* stream);
+                                int64_t ldo, int64_t prompts, int G, int x_tiled, void* stream);
 int marship_sam_upscale_masks(const void* u, int64_t ldu, const void* w3, const float* bias, const float* hyper,
                               int64_t ldh, float* masks, int64_t prompts, int G2, void* stream);
 /* The image -> token half of a two-way transformer layer at the shipped width (transformer.py:176-183, 218-240: 256 channels,
@@ -344,12 +344,16 @@ int marship_sam_upscale_masks(const void* u, int64_t ldu, const void* w3, const 
  * marship_sam_i2t_block: qin bf16 [prompts*Ni, ldq] (or [Ni, ldq] with q_shared: every prompt's stream is still the same);
  * wq bf16 [32][128][8]: entry (kc, r) = Wq[r][8kc .. 8kc+7]; wo bf16 [16][256][8]: entry (2h + g, r)[e] = Wo[r][16h + 8(e/4) + 4g + e%4];
  * prm f32 = bo [256], LayerNorm weight [256], bias [256]; resid f32 [prompts*Ni, 256] (or [Ni, 256] with resid_shared);
- * Ni a multiple of 32.  qin / c1 and resid / y may be the same buffers. */
+ * Ni a multiple of 32.  qin / c1 and resid / y may be the same buffers.
+ * `tiled` (bit 0: qin, bit 1: resid, bit 2: y and c1): the tensor is stored in the order this kernel's lanes hold it instead of
+ * row-major: for tile t of 32 tokens, lane = 32 g + n: bf16: 16-byte entry (16 t + ks) 64 + lane = channels 16 ks + 8 g .. + 7 of
+ * token 32 t + n; f32: entry ((8 t + mb) 4 + i) 64 + lane = channels 32 mb + 8 i + 4 g .. + 3.  Every load and store is then 1 KB
+ * contiguous a wave.  marship_sam_t2i_block and marship_sam_upscale_ln_gelu read the bf16 form with x_tiled = 1. */
 int marship_sam_i2t_kv_operands(const void* k, int64_t ldk, const void* v, int64_t ldv, int prompts, int Tk, void* kv_ops,
                                 void* stream);
 int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void* wq, const void* wo, const float* qbias,
                           const float* prm, const void* kv_ops, int Tk, const float* resid, int resid_shared, int prompts,
-                          int Ni, float eps, float* y, void* c1, void* stream);
+                          int Ni, float eps, float* y, void* c1, int tiled, void* stream);
 /* The token -> image attention of a two-way transformer layer at the shipped width (transformer.py:160-166, 192-197, 218-240:
  * 256 channels, eight heads of 16 dims, at most eight prompt tokens; bf16 operands) with the key and value projections of the
  * image-side stream made inside the kernel:  k = (x + key_pe) Wk^T + bk, v = x Wv^T + bv, out = softmax(q k^T / 4) v per head.
@@ -361,7 +365,7 @@ int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void
  * image token cancels in the softmax); bv f32 [128]; out bf16 [prompts*Tq, ldo] (columns 0 .. 127).  Ni a multiple of 32. */
 int marship_sam_t2i_q_operands(const void* q, int64_t ldq, int prompts, int Tq, void* q_ops, void* stream);
 int marship_sam_t2i_block(const void* x, int64_t ldx, const void* wk, const void* wv, const void* kpe_ops, const float* bv,
-                          const void* q_ops, int prompts, int Ni, int Tq, void* out, int64_t ldo, void* stream);
+                          const void* q_ops, int prompts, int Ni, int Tq, void* out, int64_t ldo, int x_tiled, void* stream);
 /* masks[b, m, p] = sum_c hyper[b, m, c] * up[b*P + p, c], four masks a prompt, C <= 64 channels (mask_decoder.py:141-143:
  * hyper_in @ upscaled_embedding); hyper f32 [B*4, ldh], up f32 [B*P, ldu], masks f32 [B, 4, P]. */
 int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int64_t ldu, float* masks, int B,

@@ -74,10 +74,17 @@ __global__ __launch_bounds__(512) void i2t_kv_operands_kernel(const __bf16* __re
 // wave w of workgroup g owns the tiles [(8 g + w) per, (8 g + w + 1) per) of 32 tokens.
 // qin / c1 and resid / y may be the same buffers: a tile reads its rows before it writes them and no other tile touches them.
 // All loads of a tile come before its first store: a wait for a load behind stores would also wait for those stores.
+// `tiled` (bit 0: qin, bit 1: resid, bit 2: y and c1): that tensor is not row-major but in the order the lanes of this
+// kernel hold it - for tile t of 32 tokens, bf16: 16-byte entry (16 t + ks) 64 + lane = the eight channels 16 ks + 8 half of
+// token 32 t + n; f32: entry ((8 t + mb) 4 + i) 64 + lane = the four channels 32 mb + 8 i + 4 half.  Row-major, a store of
+// this kernel is 32 bytes a token row (partial lines; the f32 stream went out at under 3 TB/s); tiled, every load and
+// store is 1 KB contiguous a wave.  The consumers that read the stream with the same lane mapping (this kernel in the
+// next layer, the token -> image block, the first upscaling kernel) take the tiled form; a tiled qin / resid is never
+// shared between prompts.
 __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64_t ldq, int q_shared, const __bf16* __restrict__ wq,
                                                         const __bf16* __restrict__ wo, const float* __restrict__ qbias, const float* __restrict__ prm,
                                                         const bf16x8* __restrict__ kv, int Tk, const float* resid, int resid_shared, int Ni,
-                                                        float eps, float* y, __bf16* c1, int64_t ntiles, int64_t per) {
+                                                        float eps, float* y, __bf16* c1, int64_t ntiles, int64_t per, int tiled) {
     __shared__ __align__(16) unsigned char smem[LDS_WQ + LDS_WO + NPRM * 4];
     bf16x8* sWq = (bf16x8*)smem;                        // [32][128]
     bf16x8* sWo = (bf16x8*)(smem + LDS_WQ);             // [16][256]
@@ -112,7 +119,8 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64
             const float* qb = qbias + (int64_t)pl * W + half * 4;
             bf16x8 xb[C / 16];
 #pragma unroll
-            for (int ks = 0; ks < C / 16; ++ks) xb[ks] = *(const bf16x8*)(xp + ks * 16);
+            for (int ks = 0; ks < C / 16; ++ks)
+                xb[ks] = (tiled & 1) ? ((const bf16x8*)qin)[(t * 16 + ks) * 64 + lane] : *(const bf16x8*)(xp + ks * 16);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 f32x16 acc = (f32x16)(0.f);
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64
         for (int mb = 0; mb < C / 32; ++mb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const f32x4 r = *(const f32x4*)(rp + mb * 32 + i * 8);
+                const f32x4 r = (tiled & 2) ? ((const f32x4*)resid)[((t * 8 + mb) * 4 + i) * 64 + lane] : *(const f32x4*)(rp + mb * 32 + i * 8);
                 const f32x4 bo = *(const f32x4*)(sBo + mb * 32 + i * 8 + half * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -201,14 +209,18 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const __bf16* qin, int64
                         v[j] = fmaf(acc[mb][4 * i + j] * rstd, lw[j], lb[j]);
                         a1[u][j] = (__bf16)v[j];
                     }
-                    if (yp) *(f32x4*)(yp + col) = v;
+                    if (yp) {
+                        if (tiled & 4) ((f32x4*)y)[((t * 8 + mb) * 4 + i) * 64 + lane] = v;
+                        else *(f32x4*)(yp + col) = v;
+                    }
                 }
                 // the half-waves trade halves: the lower lane ends with the eight channels of group 2 rpair, the upper with 2 rpair + 1
                 const v2i32 ai = __builtin_bit_cast(v2i32, a1[0]), bi = __builtin_bit_cast(v2i32, a1[1]);
                 const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)ai[0], (unsigned)bi[0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)ai[1], (unsigned)bi[1], false, false);
                 const v4i32 o = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
-                *(v4i32*)(c1 + tok * C + mb * 32 + 8 * (2 * rpair + half)) = o;
+                if (tiled & 4) ((v4i32*)c1)[(t * 16 + 2 * mb + rpair) * 64 + lane] = o;
+                else *(v4i32*)(c1 + tok * C + mb * 32 + 8 * (2 * rpair + half)) = o;
             }
     }
 }
@@ -227,11 +239,13 @@ extern "C" int marship_sam_i2t_kv_operands(const void* k, int64_t ldk, const voi
 
 extern "C" int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void* wq, const void* wo, const float* qbias,
                                      const float* prm, const void* kv_ops, int Tk, const float* resid, int resid_shared, int prompts, int Ni,
-                                     float eps, float* y, void* c1, void* stream) {
+                                     float eps, float* y, void* c1, int tiled, void* stream) {
     MARS_CHECK(qin && wq && wo && qbias && prm && kv_ops && resid && c1, "sam_i2t_block: null pointer");
     MARS_CHECK(prompts > 0 && Ni > 0 && Ni % 32 == 0 && Tk > 0 && Tk <= 8, "sam_i2t_block: %d prompts, %d image tokens (a multiple of 32), %d prompt tokens (1 .. 8)",
                prompts, Ni, Tk);
     MARS_CHECK(ldq >= C && ldq % 8 == 0, "sam_i2t_block: row stride %lld", (long long)ldq);
+    MARS_CHECK(tiled >= 0 && tiled <= 7 && !((tiled & 1) && (q_shared || ldq != C)) && !((tiled & 2) && resid_shared),
+               "sam_i2t_block: tiled %d (a tiled input is per prompt, 256 values a token)", tiled);
     MARS_CHECK((((uintptr_t)qin | (uintptr_t)wq | (uintptr_t)wo | (uintptr_t)prm | (uintptr_t)kv_ops | (uintptr_t)resid | (uintptr_t)qbias | (uintptr_t)y |
                  (uintptr_t)c1) % 16) == 0, "sam_i2t_block: 16-byte alignment");
     static const int cus = [] { int dev = 0, c = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256; return c; }();
@@ -241,7 +255,7 @@ extern "C" int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared,
     const int64_t per = (ntiles + waves - 1) / waves;
     const unsigned grid = (unsigned)((ntiles + per * 8 - 1) / (per * 8));
     hipLaunchKernelGGL(i2t_block_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const __bf16*)qin, ldq, q_shared, (const __bf16*)wq,
-                       (const __bf16*)wo, qbias, prm, (const bf16x8*)kv_ops, Tk, resid, resid_shared, Ni, eps, y, (__bf16*)c1, ntiles, per);
+                       (const __bf16*)wo, qbias, prm, (const bf16x8*)kv_ops, Tk, resid, resid_shared, Ni, eps, y, (__bf16*)c1, ntiles, per, tiled);
     MARS_LAUNCH_CHECK();
     return 0;
 }

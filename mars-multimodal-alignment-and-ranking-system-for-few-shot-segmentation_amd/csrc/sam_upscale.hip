@@ -60,7 +60,7 @@ constexpr int UP0_LDS_W = 4 * UP0_C * UP0_K * 2; // bytes of its weight as bf16
 // wave w of workgroup g walks the 32-token tiles 8 g + w, 8 g + w + 8 gridDim, ...
 __global__ __launch_bounds__(512) void upscale_ln_gelu_kernel(const __bf16* __restrict__ x, int64_t ldx, const __bf16* __restrict__ w0,
                                                               const float* __restrict__ prm, float eps, __bf16* __restrict__ out, int64_t ldo,
-                                                              int G, int64_t ntiles) {
+                                                              int G, int64_t ntiles, int x_tiled) {
     __shared__ __align__(16) unsigned char smem[UP0_LDS_W + 3 * UP0_C * 4];
     bf16x8* sW = (bf16x8*)smem;
     float* sP = (float*)(smem + UP0_LDS_W);
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(512) void upscale_ln_gelu_kernel(const __bf16* __re
         const __bf16* xp = x + tok * ldx + half * 8;
         bf16x8 xb[UP0_K / 16];
 #pragma unroll
-        for (int ks = 0; ks < UP0_K / 16; ++ks) xb[ks] = *(const bf16x8*)(xp + ks * 16);
+        for (int ks = 0; ks < UP0_K / 16; ++ks)       // (x_tiled: the order sam_i2t_block leaves it in, 1 KB a load)
+            xb[ks] = x_tiled ? ((const bf16x8*)x)[(t * 16 + ks) * 64 + lane] : *(const bf16x8*)(xp + ks * 16);
         const int64_t b = tok / Ni;
         const int pl = (int)(tok - b * Ni), y = pl / G, xx = pl - y * G;
 #pragma unroll 1
@@ -207,18 +208,19 @@ __global__ __launch_bounds__(256) void upscale_masks_kernel(const __bf16* __rest
 }  // namespace
 
 extern "C" int marship_sam_upscale_ln_gelu(const void* x, int64_t ldx, const void* w0, const float* prm, float eps, void* out, int64_t ldo,
-                                           int64_t prompts, int G, void* stream) {
+                                           int64_t prompts, int G, int x_tiled, void* stream) {
     MARS_CHECK(x && w0 && prm && out && prompts > 0 && G > 0, "sam_upscale_ln_gelu: bad arguments");
     const int64_t tokens = prompts * G * G;
     MARS_CHECK(tokens % 32 == 0, "sam_upscale_ln_gelu: %lld tokens (a multiple of 32)", (long long)tokens);
     MARS_CHECK(ldx >= UP0_K && ldx % 8 == 0 && ldo >= UP0_C && ldo % 8 == 0 && (((uintptr_t)x | (uintptr_t)w0 | (uintptr_t)out | (uintptr_t)prm) % 16) == 0,
                "sam_upscale_ln_gelu: rows must be 16-byte aligned and hold 256 / 64 channels");
+    MARS_CHECK(!x_tiled || ldx == UP0_K, "sam_upscale_ln_gelu: a tiled x has 256 values a token");
     static const int cus = [] { int dev = 0, c = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256; return c; }();
     const int64_t ntiles = tokens / 32;
     const int64_t want = (ntiles + 7) / 8;
     const unsigned grid = (unsigned)(want < cus ? want : cus);
     hipLaunchKernelGGL(upscale_ln_gelu_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const __bf16*)x, ldx, (const __bf16*)w0, prm, eps,
-                       (__bf16*)out, ldo, G, ntiles);
+                       (__bf16*)out, ldo, G, ntiles, x_tiled);
     MARS_LAUNCH_CHECK();
     return 0;
 }

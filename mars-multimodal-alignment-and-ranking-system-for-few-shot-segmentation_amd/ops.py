@@ -726,7 +726,8 @@ def layernorm_act_rows(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: t
               "marship_layernorm_act_rows")
 
 
-def sam_upscale_ln_gelu(x: torch.Tensor, w0: torch.Tensor, prm: torch.Tensor, out: torch.Tensor, prompts: int, G: int, eps: float = 1e-6):
+def sam_upscale_ln_gelu(x: torch.Tensor, w0: torch.Tensor, prm: torch.Tensor, out: torch.Tensor, prompts: int, G: int, eps: float = 1e-6,
+                        x_tiled: bool = False):
     """ConvTranspose2d(256, 64, 2, 2) + LayerNorm2d + GELU: x bf16 [prompts*G*G, >= 256] -> out bf16 [prompts*4*G*G, >= 64];
     w0 bf16 [32, 256, 8] (runs of eight K, run-major), prm f32 [3, 64]."""
     _dev(x, w0, prm, out)
@@ -734,7 +735,7 @@ def sam_upscale_ln_gelu(x: torch.Tensor, w0: torch.Tensor, prm: torch.Tensor, ou
     _req(x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1 and x.shape[0] >= prompts * G * G and x.shape[1] >= 256
          and out.shape[0] >= prompts * 4 * G * G and out.shape[1] >= 64, "sam_upscale_ln_gelu: activations")
     _req(w0.is_contiguous() and w0.numel() == 256 * 256 and prm.is_contiguous() and prm.numel() == 192, "sam_upscale_ln_gelu: parameters")
-    hip.check(hip.lib().marship_sam_upscale_ln_gelu(ptr(x), x.stride(0), ptr(w0), ptr(prm), eps, ptr(out), out.stride(0), prompts, G, stream()),
+    hip.check(hip.lib().marship_sam_upscale_ln_gelu(ptr(x), x.stride(0), ptr(w0), ptr(prm), eps, ptr(out), out.stride(0), prompts, G, int(x_tiled), stream()),
               "marship_sam_upscale_ln_gelu")
 
 
@@ -764,9 +765,10 @@ def sam_i2t_kv_operands(k: torch.Tensor, v: torch.Tensor, prompts: int, Tk: int,
 
 
 def sam_i2t_block(qin: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, qbias: torch.Tensor, prm: torch.Tensor, kv_ops: torch.Tensor, Tk: int,
-                  resid: torch.Tensor, prompts: int, Ni: int, eps: float, y: Optional[torch.Tensor], c1: torch.Tensor):
+                  resid: torch.Tensor, prompts: int, Ni: int, eps: float, y: Optional[torch.Tensor], c1: torch.Tensor, tiled: int = 0):
     """Image -> token attention block + norm4 + the bf16 copy of the result in one pass (see marship_sam_i2t_block).  qin with Ni
-    rows (instead of prompts*Ni) is shared by every prompt, and so is resid with Ni rows; qbias f32 [Ni, 128] = key_pe Wq^T + bq."""
+    rows (instead of prompts*Ni) is shared by every prompt, and so is resid with Ni rows; qbias f32 [Ni, 128] = key_pe Wq^T + bq.
+    ``tiled`` bit 0 / 1 / 2: qin / resid / the outputs are in the kernel's own lane order instead of row-major (same sizes)."""
     _dev(qin, wq, wo, qbias, prm, kv_ops, resid, y, c1)
     rows = prompts * Ni
     _req(qin.dtype == wq.dtype == wo.dtype == kv_ops.dtype == c1.dtype == torch.bfloat16, "sam_i2t_block: bf16 operands")
@@ -780,7 +782,7 @@ def sam_i2t_block(qin: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, qbias: 
         _req(t.is_contiguous() and t.numel() == rows * 256, "sam_i2t_block: outputs")
     hip.check(hip.lib().marship_sam_i2t_block(ptr(qin), qin.stride(0), int(qin.shape[0] == Ni and prompts > 1), ptr(wq), ptr(wo), ptr(qbias), ptr(prm),
                                               ptr(kv_ops), Tk, ptr(resid), int(resid.shape[0] == Ni and prompts > 1), prompts, Ni, eps, ptr(y), ptr(c1),
-                                              stream()), "marship_sam_i2t_block")
+                                              tiled, stream()), "marship_sam_i2t_block")
 
 
 def sam_t2i_q_operands(q: torch.Tensor, prompts: int, Tq: int, q_ops: torch.Tensor):
@@ -806,7 +808,7 @@ def sam_t2i_kpe_operands(kpe: torch.Tensor) -> torch.Tensor:
 
 
 def sam_t2i_block(x: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, kpe_ops: torch.Tensor, bv: torch.Tensor, q_ops: torch.Tensor, prompts: int,
-                  Ni: int, Tq: int, out: torch.Tensor):
+                  Ni: int, Tq: int, out: torch.Tensor, x_tiled: bool = False):
     """Token -> image attention with the key / value projections of the stream made inside the kernel (see marship_sam_t2i_block)."""
     _dev(x, wk, wv, kpe_ops, bv, q_ops, out)
     _req(x.dtype == wk.dtype == wv.dtype == kpe_ops.dtype == q_ops.dtype == out.dtype == torch.bfloat16 and bv.dtype == torch.float32, "sam_t2i_block: dtypes")
@@ -816,7 +818,7 @@ def sam_t2i_block(x: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, kpe_ops: 
     _req(q_ops.is_contiguous() and q_ops.numel() >= prompts * 8 * 64 * 8, "sam_t2i_block: q_ops")
     _req(out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= prompts * Tq and out.shape[1] >= 128, "sam_t2i_block: out")
     hip.check(hip.lib().marship_sam_t2i_block(ptr(x), x.stride(0), ptr(wk), ptr(wv), ptr(kpe_ops), ptr(bv), ptr(q_ops), prompts, Ni, Tq, ptr(out),
-                                              out.stride(0), stream()), "marship_sam_t2i_block")
+                                              out.stride(0), int(x_tiled), stream()), "marship_sam_t2i_block")
 
 
 def hyper_product(hyper: torch.Tensor, up: torch.Tensor, masks: torch.Tensor, B: int, P: int, C: int):

@@ -474,7 +474,8 @@ class MaskDecoder:
         self._attn.run(q, 0, k, 0, v, 0, o, nb, A.H, Tq, Tk, A.hdp, 1.0 / math.sqrt(A.hd))
         ops.linear(o, A.o.w, out, bias=A.o.b, residual=residual)
 
-    def _t2i_fused(self, A: _DecAttn, kpe_ops: torch.Tensor, tag: str, q_in, x, nb: int, Tq: int, Ni: int, out: torch.Tensor, residual):
+    def _t2i_fused(self, A: _DecAttn, kpe_ops: torch.Tensor, tag: str, q_in, x, nb: int, Tq: int, Ni: int, out: torch.Tensor, residual,
+                   x_tiled: bool = False):
         """Token -> image attention of ``nb`` prompts against their image streams x (bf16 keys, [nb*Ni, C]) with the key and
         value projections inside the attention kernel; then the output projection (+ residual) as in _attention."""
         q = self._buf(tag + "qs", (nb * Tq, 128))
@@ -482,7 +483,7 @@ class MaskDecoder:
         qo = self._buf(tag + "qo", (nb, 8, 64, 8))
         ops.sam_t2i_q_operands(q, nb, Tq, qo)
         o = self._buf(tag + "os", (nb * Tq, 128))
-        ops.sam_t2i_block(x, A.wk_runs, A.wv_runs, kpe_ops, A.vs.b, qo, nb, Ni, Tq, o)
+        ops.sam_t2i_block(x, A.wk_runs, A.wv_runs, kpe_ops, A.vs.b, qo, nb, Ni, Tq, o, x_tiled=x_tiled)
         ops.linear(o, A.os.w, out, bias=A.os.b, residual=residual)
 
     def _pe_terms(self, pe_tokens: torch.Tensor) -> Dict[tuple, torch.Tensor]:
@@ -552,7 +553,13 @@ class MaskDecoder:
         pe_terms = self._pe_terms(dense_pe_tokens) if fused_i2t else None
         # (a workgroup of the fused token -> image kernel serves four prompts: small batches leave the GPU empty and keep the
         # separate projection and attention launches)
-        fused_t2i = fused_i2t and B >= int(os.environ.get("MARS_SAM_FUSED_T2I_MIN", "256"))
+        fused_t2i = (fused_i2t and B >= int(os.environ.get("MARS_SAM_FUSED_T2I_MIN", "256"))
+                     and all(("kops", i) in pe_terms for i in range(1, len(self.layers) + 1)))
+        up_fused = self.fused_up and (2 * G) % 32 == 0 and B <= 65535
+        # When every reader of the per-prompt image stream is one of the fused kernels (they all hold a 32-token tile the same
+        # way), the stream is kept in that lane order instead of row-major after the first layer: loads and stores of 1 KB a
+        # wave instead of 32 bytes a token row.  MARS_SAM_TILED=0 keeps it row-major.
+        tiled = share0 and fused_t2i and up_fused and os.environ.get("MARS_SAM_TILED", "1") != "0"
         kd = None if fused_i2t else self._buf("kd", (B * Ni, C))          # (keys + key_pe: only the separate launches read it)
         if not share0:
             ops.stream_copies(Kf, None if fused_i2t else kd, vd, add=None if fused_i2t else dense_pe_tokens)
@@ -574,8 +581,8 @@ class MaskDecoder:
             ops.add_cast(Q, pe2, qd)
             if share0 and i == 0:
                 self._attention(L["t2i"], "t2i", qd, kd0, vd0, B, Nt, Ni, Q, Q, kv_shared=True)
-            elif fused_i2t and fused_t2i and ("kops", i) in pe_terms:
-                self._t2i_fused(L["t2i"], pe_terms[("kops", i)], "t2i", qd, vd, B, Nt, Ni, Q, Q)
+            elif fused_t2i:
+                self._t2i_fused(L["t2i"], pe_terms[("kops", i)], "t2i", qd, vd, B, Nt, Ni, Q, Q, x_tiled=tiled)
             elif fused_i2t:
                 self._attention(L["t2i"], "t2i", qd, vd, vd, B, Nt, Ni, Q, Q, k_pe=pe_terms[("k", i)])
             else:
@@ -599,7 +606,7 @@ class MaskDecoder:
                 ops.sam_i2t_kv_operands(k, v, B, Nt, kvo)
                 first0 = share0 and i == 0
                 ops.sam_i2t_block(vd0 if first0 else vd, Fz["wq"], Fz["wo"], pe_terms[("q", i)], Fz["prm"], kvo, Nt, src0 if first0 else Kf, B, Ni,
-                                  1e-5, None if last else Kf, vd)
+                                  1e-5, None if last else Kf, vd, tiled=(4 | (0 if first0 else 3)) if tiled else 0)
                 continue
             if share0 and i == 0:
                 self._attention(L["i2t"], "i2t", kd0, qd, td, B, Ni, Nt, Kf, src0, q_shared=True)
@@ -608,8 +615,8 @@ class MaskDecoder:
             ops.stream_copies(Kf, kd, vd, add=dense_pe_tokens, norm=L["n4"], eps=1e-5,
                               write_back=i + 1 < len(self.layers))        # (nothing reads the f32 stream after the last layer)
         ops.add_cast(Q, pe2, qd)
-        if fused_i2t and fused_t2i and ("kops", len(self.layers)) in pe_terms:
-            self._t2i_fused(self.final, pe_terms[("kops", len(self.layers))], "fin", qd, vd, B, Nt, Ni, Q, Q)
+        if fused_t2i:
+            self._t2i_fused(self.final, pe_terms[("kops", len(self.layers))], "fin", qd, vd, B, Nt, Ni, Q, Q, x_tiled=tiled)
         elif fused_i2t:
             self._attention(self.final, "fin", qd, vd, vd, B, Nt, Ni, Q, Q, k_pe=pe_terms[("k", len(self.layers))])
         else:
@@ -620,10 +627,10 @@ class MaskDecoder:
         # pixel-shuffled layout: one batched GEMM per output-row parity (batch = (prompt, input row))
         C4, C8 = C // 4, C // 8
         G2 = 2 * G
-        fused = self.fused_up and G2 % 32 == 0 and B <= 65535
+        fused = up_fused
         u1d = self._buf("u1d", (B * 4 * Ni, _pad_to(C4, 64)))              # (pad columns stay zero)
         if fused:
-            ops.sam_upscale_ln_gelu(vd, self.up0_runs, self.up0_prm, u1d, B, G, 1e-6)
+            ops.sam_upscale_ln_gelu(vd, self.up0_runs, self.up0_prm, u1d, B, G, 1e-6, x_tiled=tiled)
         else:
             u1 = self._buf("u1", (B * 4 * Ni, C4), f32)
             for dy in (0, 1):

@@ -1206,3 +1206,58 @@ def test_sam_t2i_block_matches_torch(pkg, cuda, prompts, Ni, Tq):
     s = torch.einsum("bqhd,bnhd->bhqn", qh, k) * 0.25
     ref = torch.einsum("bhqn,bnhd->bqhd", torch.softmax(s, -1), v).reshape(prompts * Tq, 128)
     assert float((out.double() - ref).abs().max()) <= 3e-2                   # |v| ~ 1: roundings of k, p, v to bf16 and of the result
+
+
+def _tile_bf16(x):
+    """Row-major [tokens, 256] -> the lane order of the fused mask-decoder kernels: entry (16 t + ks) 64 + 32 g + n = channels 16 ks + 8 g .. of token 32 t + n."""
+    T = x.shape[0] // 32
+    return x.view(T, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1, 256)
+
+
+def _tile_f32(y):
+    """Row-major [tokens, 256] f32 -> entry ((8 t + mb) 4 + i) 64 + 32 g + n = channels 32 mb + 8 i + 4 g .. of token 32 t + n."""
+    T = y.shape[0] // 32
+    return y.view(T, 32, 8, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(-1, 256)
+
+
+def test_sam_fused_blocks_in_lane_order_equal_row_major(pkg, cuda):
+    """The three fused kernels read and write the per-prompt image stream either row-major or in their own lane order:
+    same values, bit for bit, only the addresses differ."""
+    bf = torch.bfloat16
+    prompts, Ni, Tk = 3, 128, 7
+    rows = prompts * Ni
+    slot = torch.tensor([16 * h + 8 * (e // 4) + 4 * g + e % 4 for h in range(8) for g in range(2) for e in range(8)], device=cuda)
+    runs = lambda w: w.view(128, 32, 8).permute(1, 0, 2).contiguous()
+    wq, wo = (_rand((128, 256), 71, cuda) * 0.08).to(bf), (_rand((256, 128), 72, cuda) * 0.1).to(bf)
+    wo_runs = wo[:, slot].view(256, 16, 8).permute(1, 0, 2).contiguous()
+    qbias, prm = _rand((Ni, 128), 73, cuda) * 0.5, torch.cat([_rand((256,), 74, cuda) * 0.2, _rand((256,), 75, cuda) * 0.3 + 1, _rand((256,), 76, cuda) * 0.2]).contiguous()
+    kvo = torch.empty(prompts, 8, 64, 2, 8, device=cuda, dtype=bf)
+    pkg.ops.sam_i2t_kv_operands(_rand((prompts * Tk, 128), 77, cuda).to(bf), _rand((prompts * Tk, 128), 78, cuda).to(bf), prompts, Tk, kvo)
+    x, r = _rand((rows, 256), 79, cuda).to(bf), _rand((rows, 256), 80, cuda)
+    # image -> token block: row-major in and out; then tiled out; then tiled in and out (in place, as the decoder runs it)
+    y0, c0 = torch.empty(rows, 256, device=cuda), torch.empty(rows, 256, device=cuda, dtype=bf)
+    pkg.ops.sam_i2t_block(x, runs(wq), wo_runs, qbias, prm, kvo, Tk, r, prompts, Ni, 1e-5, y0, c0)
+    y1, c1 = torch.empty_like(y0), torch.empty_like(c0)
+    pkg.ops.sam_i2t_block(x, runs(wq), wo_runs, qbias, prm, kvo, Tk, r, prompts, Ni, 1e-5, y1, c1, tiled=4)
+    assert torch.equal(y1, _tile_f32(y0)) and torch.equal(c1, _tile_bf16(c0))
+    xt, rt = _tile_bf16(x), _tile_f32(r)
+    pkg.ops.sam_i2t_block(xt, runs(wq), wo_runs, qbias, prm, kvo, Tk, rt, prompts, Ni, 1e-5, rt, xt, tiled=7)
+    assert torch.equal(rt, _tile_f32(y0)) and torch.equal(xt, _tile_bf16(c0))
+    # token -> image block
+    Tq = 7
+    wk, wv, bv = (_rand((128, 256), 81, cuda) * 0.06).to(bf), (_rand((128, 256), 82, cuda) * 0.06).to(bf), _rand((128,), 83, cuda) * 0.3
+    kpe_ops = pkg.ops.sam_t2i_kpe_operands(_rand((Ni, 128), 84, cuda))
+    q_ops = torch.empty(prompts, 8, 64, 8, device=cuda, dtype=bf)
+    pkg.ops.sam_t2i_q_operands((_rand((prompts * Tq, 128), 85, cuda) * 1.5).to(bf), prompts, Tq, q_ops)
+    o0, o1 = (torch.empty(prompts * Tq, 128, device=cuda, dtype=bf) for _ in range(2))
+    pkg.ops.sam_t2i_block(x, runs(wk), runs(wv), kpe_ops, bv, q_ops, prompts, Ni, Tq, o0)
+    pkg.ops.sam_t2i_block(_tile_bf16(x), runs(wk), runs(wv), kpe_ops, bv, q_ops, prompts, Ni, Tq, o1, x_tiled=True)
+    assert torch.equal(o0, o1)
+    # first upscaling kernel (Ni = 128 is not a square grid: 2 prompts of an 8 x 8 grid)
+    w0 = ((_rand((256, 256), 86, cuda) * 0.08).to(bf)).view(256, 32, 8).permute(1, 0, 2).contiguous()
+    up_prm = torch.stack([_rand((64,), 87, cuda) * 0.2, _rand((64,), 88, cuda) * 0.3 + 1.0, _rand((64,), 89, cuda) * 0.2]).contiguous()
+    xs = x[:2 * 64].contiguous()
+    u0, u1 = (torch.empty(2 * 4 * 64, 64, device=cuda, dtype=bf) for _ in range(2))
+    pkg.ops.sam_upscale_ln_gelu(xs, w0, up_prm, u0, 2, 8, 1e-6)
+    pkg.ops.sam_upscale_ln_gelu(_tile_bf16(xs), w0, up_prm, u1, 2, 8, 1e-6, x_tiled=True)
+    assert torch.equal(u0, u1)
