@@ -362,10 +362,12 @@ int marship_sam_i2t_block(const void* qin, int64_t ldq, int q_shared, const void
  * marship_sam_t2i_block: x bf16 [prompts*Ni, ldx] (the bf16 copy of keys); wk, wv bf16 [32][128][8]: entry (kc, r) = W[r][8kc .. 8kc+7];
  * kpe_ops bf16 [Ni/32][8][64][8]: key_pe Wk^T in operand order: entry (tile, 2 pair + s, lane (token n, half g))[e] =
  * (key_pe Wk^T)[32 tile + n][16 (2 pair + s) + 8 (e/4) + 4 g + e%4] (bk may be included or not: a term that is the same for every
- * image token cancels in the softmax); bv f32 [128]; out bf16 [prompts*Tq, ldo] (columns 0 .. 127).  Ni a multiple of 32. */
+ * image token cancels in the softmax); bv f32 [128]; out bf16 [prompts*Tq, ldo] (columns 0 .. 127).  Ni a multiple of 32.
+ * x_shared: x is [Ni, ldx], one stream for every prompt (the first layer without mask prompts). */
 int marship_sam_t2i_q_operands(const void* q, int64_t ldq, int prompts, int Tq, void* q_ops, void* stream);
 int marship_sam_t2i_block(const void* x, int64_t ldx, const void* wk, const void* wv, const void* kpe_ops, const float* bv,
-                          const void* q_ops, int prompts, int Ni, int Tq, void* out, int64_t ldo, int x_tiled, void* stream);
+                          const void* q_ops, int prompts, int Ni, int Tq, void* out, int64_t ldo, int x_tiled, int x_shared,
+                          void* stream);
 /* masks[b, m, p] = sum_c hyper[b, m, c] * up[b*P + p, c], four masks a prompt, C <= 64 channels (mask_decoder.py:141-143:
  * hyper_in @ upscaled_embedding); hyper f32 [B*4, ldh], up f32 [B*P, ldu], masks f32 [B, 4, P]. */
 int marship_hyper_product(const float* hyper, int64_t ldh, const float* up, int64_t ldu, float* masks, int B,

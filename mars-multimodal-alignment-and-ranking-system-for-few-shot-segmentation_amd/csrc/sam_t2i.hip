@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void t2i_q_operands_kernel(const __bf16* __res
 __global__ __launch_bounds__(512) void t2i_block_kernel(const __bf16* __restrict__ x, int64_t ldx, const __bf16* __restrict__ wk,
                                                         const __bf16* __restrict__ wv, const bf16x8* __restrict__ kpe, const float* __restrict__ bv,
                                                         const bf16x8* __restrict__ qops, int prompts, int Ni, int Tq, __bf16* __restrict__ out,
-                                                        int64_t ldo, int x_tiled) {
+                                                        int64_t ldo, int x_tiled, int x_shared) {
     __shared__ __align__(16) unsigned char smem[2 * LDS_W];
     bf16x8* sWk = (bf16x8*)smem;                       // [32][128]
     bf16x8* sWv = (bf16x8*)(smem + LDS_W);             // [32][128]
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void t2i_block_kernel(const __bf16* __restrict
             int opaque = 0;
             asm volatile("" : "+v"(opaque));
             const bf16x8 *tWk = sWk + opaque, *tWv = sWv + opaque;
-            const __bf16* xp = x + (b * Ni + (int64_t)t * 32 + n) * ldx + half * 8;
+            const __bf16* xp = x + ((x_shared ? 0 : b * Ni) + (int64_t)t * 32 + n) * ldx + half * 8;      // (x_shared: one stream for every prompt)
             bf16x8 xb[C / 16];
 #pragma unroll
             for (int ks = 0; ks < C / 16; ++ks)         // (x_tiled: the order sam_i2t_block leaves it in, 1 KB a load)
@@ -208,16 +208,16 @@ extern "C" int marship_sam_t2i_q_operands(const void* q, int64_t ldq, int prompt
 }
 
 extern "C" int marship_sam_t2i_block(const void* x, int64_t ldx, const void* wk, const void* wv, const void* kpe_ops, const float* bv,
-                                     const void* q_ops, int prompts, int Ni, int Tq, void* out, int64_t ldo, int x_tiled, void* stream) {
+                                     const void* q_ops, int prompts, int Ni, int Tq, void* out, int64_t ldo, int x_tiled, int x_shared, void* stream) {
     MARS_CHECK(x && wk && wv && kpe_ops && bv && q_ops && out, "sam_t2i_block: null pointer");
     MARS_CHECK(prompts > 0 && Ni > 0 && Ni % 32 == 0 && Tq > 0 && Tq <= 8, "sam_t2i_block: %d prompts, %d image tokens (a multiple of 32), %d prompt tokens (1 .. 8)",
                prompts, Ni, Tq);
     MARS_CHECK(ldx >= C && ldx % 8 == 0 && ldo >= W && ldo % 4 == 0, "sam_t2i_block: row strides %lld / %lld", (long long)ldx, (long long)ldo);
-    MARS_CHECK(!x_tiled || ldx == C, "sam_t2i_block: a tiled x has 256 values a token");
+    MARS_CHECK(!x_tiled || (ldx == C && !x_shared), "sam_t2i_block: a tiled x has 256 values a token and is per prompt");
     MARS_CHECK((((uintptr_t)x | (uintptr_t)wk | (uintptr_t)wv | (uintptr_t)kpe_ops | (uintptr_t)q_ops) % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
                    ((uintptr_t)bv % 4) == 0, "sam_t2i_block: alignment");
     hipLaunchKernelGGL(t2i_block_kernel, dim3((unsigned)((prompts + 3) / 4)), dim3(512), 0, (hipStream_t)stream, (const __bf16*)x, ldx, (const __bf16*)wk,
-                       (const __bf16*)wv, (const bf16x8*)kpe_ops, bv, (const bf16x8*)q_ops, prompts, Ni, Tq, (__bf16*)out, ldo, x_tiled);
+                       (const __bf16*)wv, (const bf16x8*)kpe_ops, bv, (const bf16x8*)q_ops, prompts, Ni, Tq, (__bf16*)out, ldo, x_tiled, x_shared);
     MARS_LAUNCH_CHECK();
     return 0;
 }

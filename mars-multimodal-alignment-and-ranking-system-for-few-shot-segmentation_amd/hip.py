@@ -94,7 +94,7 @@ _SIGNATURES = {
     "marship_sam_i2t_kv_operands": [_P, _L, _P, _L, _I, _I, _P, _P],
     "marship_sam_i2t_block": [_P, _L, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P],
     "marship_sam_t2i_q_operands": [_P, _L, _I, _I, _P, _P],
-    "marship_sam_t2i_block": [_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _I, _P],
+    "marship_sam_t2i_block": [_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _I, _I, _P],
     "marship_hyper_product": [_P, _L, _P, _L, _P, _I, _L, _I, _P],
     "marship_mask_embed": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P],
     "marship_resample_mask_stats": [_P, _L, _L, _I, _I, _I, _I, _I, POINTER(MarsAxisTable), POINTER(MarsAxisTable), _I, _I, _F, _F, _P, _P, _P],

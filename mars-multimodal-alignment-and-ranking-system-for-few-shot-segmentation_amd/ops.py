@@ -809,16 +809,18 @@ def sam_t2i_kpe_operands(kpe: torch.Tensor) -> torch.Tensor:
 
 def sam_t2i_block(x: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, kpe_ops: torch.Tensor, bv: torch.Tensor, q_ops: torch.Tensor, prompts: int,
                   Ni: int, Tq: int, out: torch.Tensor, x_tiled: bool = False):
-    """Token -> image attention with the key / value projections of the stream made inside the kernel (see marship_sam_t2i_block)."""
+    """Token -> image attention with the key / value projections of the stream made inside the kernel (see marship_sam_t2i_block).
+    x with Ni rows (instead of prompts*Ni) is one stream shared by every prompt."""
     _dev(x, wk, wv, kpe_ops, bv, q_ops, out)
     _req(x.dtype == wk.dtype == wv.dtype == kpe_ops.dtype == q_ops.dtype == out.dtype == torch.bfloat16 and bv.dtype == torch.float32, "sam_t2i_block: dtypes")
-    _req(x.dim() == 2 and x.stride(1) == 1 and x.shape[0] >= prompts * Ni and x.shape[1] >= 256, "sam_t2i_block: x")
+    x_shared = prompts > 1 and x.shape[0] == Ni
+    _req(x.dim() == 2 and x.stride(1) == 1 and (x_shared or x.shape[0] >= prompts * Ni) and x.shape[1] >= 256, "sam_t2i_block: x")
     _req(wk.is_contiguous() and wk.numel() == 128 * 256 and wv.is_contiguous() and wv.numel() == 128 * 256, "sam_t2i_block: weights")
     _req(kpe_ops.is_contiguous() and kpe_ops.numel() == Ni // 32 * 8 * 64 * 8 and bv.is_contiguous() and bv.numel() == 128, "sam_t2i_block: kpe_ops / bv")
     _req(q_ops.is_contiguous() and q_ops.numel() >= prompts * 8 * 64 * 8, "sam_t2i_block: q_ops")
     _req(out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= prompts * Tq and out.shape[1] >= 128, "sam_t2i_block: out")
     hip.check(hip.lib().marship_sam_t2i_block(ptr(x), x.stride(0), ptr(wk), ptr(wv), ptr(kpe_ops), ptr(bv), ptr(q_ops), prompts, Ni, Tq, ptr(out),
-                                              out.stride(0), int(x_tiled), stream()), "marship_sam_t2i_block")
+                                              out.stride(0), int(x_tiled), int(x_shared), stream()), "marship_sam_t2i_block")
 
 
 def hyper_product(hyper: torch.Tensor, up: torch.Tensor, masks: torch.Tensor, B: int, P: int, C: int):

@@ -579,7 +579,9 @@ class MaskDecoder:
             ln(Q, L["n1"], B * Nt)
             # (2) tokens attend to the image
             ops.add_cast(Q, pe2, qd)
-            if share0 and i == 0:
+            if share0 and i == 0 and fused_t2i and ("kops", 0) in pe_terms:
+                self._t2i_fused(L["t2i"], pe_terms[("kops", 0)], "t2i", qd, vd0, B, Nt, Ni, Q, Q)          # (vd0: one stream for all prompts)
+            elif share0 and i == 0:
                 self._attention(L["t2i"], "t2i", qd, kd0, vd0, B, Nt, Ni, Q, Q, kv_shared=True)
             elif fused_t2i:
                 self._t2i_fused(L["t2i"], pe_terms[("kops", i)], "t2i", qd, vd, B, Nt, Ni, Q, Q, x_tiled=tiled)

@@ -1206,6 +1206,11 @@ def test_sam_t2i_block_matches_torch(pkg, cuda, prompts, Ni, Tq):
     s = torch.einsum("bqhd,bnhd->bhqn", qh, k) * 0.25
     ref = torch.einsum("bhqn,bnhd->bqhd", torch.softmax(s, -1), v).reshape(prompts * Tq, 128)
     assert float((out.double() - ref).abs().max()) <= 3e-2                   # |v| ~ 1: roundings of k, p, v to bf16 and of the result
+    if prompts > 1:                                                          # one stream for every prompt == that stream repeated
+        out_a, out_b = torch.empty_like(out), torch.empty_like(out)
+        pkg.ops.sam_t2i_block(x[:Ni].contiguous(), runs(wk), runs(wv), kpe_ops, bv, q_ops, prompts, Ni, Tq, out_a)
+        pkg.ops.sam_t2i_block(x[:Ni].repeat(prompts, 1), runs(wk), runs(wv), kpe_ops, bv, q_ops, prompts, Ni, Tq, out_b)
+        assert torch.equal(out_a, out_b)
 
 
 def _tile_bf16(x):

@@ -552,7 +552,7 @@ def test_fused_token_to_image_block_agrees_with_separate_launches(pkg, monkeypat
         coords = torch.as_tensor(pred.transform.apply_coords(pts, img.shape[:2]), dtype=torch.float32, device="cuda")
         masks, iou, low = pred.predict_torch(coords, torch.ones(9, 1, dtype=torch.int32, device="cuda"), multimask_output=True, return_logits=True)
         monkeypatch.setattr(pkg.ops, "sam_t2i_block", orig)
-        assert len(calls) == (len(sam.mask_decoder.layers) if flag == "1" else 0)      # every layer after the first, and the final attention
+        assert len(calls) == (len(sam.mask_decoder.layers) + 1 if flag == "1" else 0)  # every layer and the final attention
         res.append((masks.float().clone(), iou.float().clone(), low.float().clone()))
     (m1, i1, l1), (m0, i0, l0) = res
     scale = float(l0.abs().max())
