@@ -477,7 +477,7 @@ __device__ __forceinline__ float banded_sum(const float* __restrict__ v, int str
         float x[KT], wk[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) {                   // all reads requested before the first is used
-            x[k] = v[min(m0 + k, last) * stride];
+            x[k] = v[max(min(m0 + k, last), 0) * stride];
             wk[k] = k < kmax ? w[k] : 0.f;                // (a row of the table holds kmax weights)
         }
 #pragma unroll
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void resample_bands_kernel(const float* __rest
             if (threadIdx.x == 0) { sr[0] = r0; sr[1] = min(min(r1, L), r0 + max_rows); }
         }
         __syncthreads();
-        const int r0 = sr[0], nr = max(sr[1] - r0, 0);
+        const int r0 = min(sr[0], L - 1), nr = max(sr[1] - r0, 0);        // (a band whose outputs read nothing: nr = 0, the sums are empty)
         // the rows are consecutive in memory: one coalesced copy
         const float* sp = src + (int64_t)r0 * L;
         if ((L & 3) == 0 && ((uintptr_t)sp & 15) == 0) {
