@@ -553,7 +553,7 @@ class MaskDecoder:
         pe_terms = self._pe_terms(dense_pe_tokens) if fused_i2t else None
         # (a workgroup of the fused token -> image kernel serves four prompts: small batches leave the GPU empty and keep the
         # separate projection and attention launches)
-        fused_t2i = (fused_i2t and B >= int(os.environ.get("MARS_SAM_FUSED_T2I_MIN", "256"))
+        fused_t2i = (fused_i2t and B >= int(os.environ.get("MARS_SAM_FUSED_T2I_MIN", "512"))
                      and all(("kops", i) in pe_terms for i in range(1, len(self.layers) + 1)))
         up_fused = self.fused_up and (2 * G) % 32 == 0 and B <= 65535
         # When every reader of the per-prompt image stream is one of the fused kernels (they all hold a 32-token tile the same
