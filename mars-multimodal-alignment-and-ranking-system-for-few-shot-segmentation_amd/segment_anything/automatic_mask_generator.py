@@ -82,10 +82,13 @@ class SamAutomaticMaskGenerator:
         L = 4 * pr.model.prompt_encoder.image_embedding_size[0]
         return os.environ.get("MARS_SAM_FUSED_POST", "1") != "0" and pr.model.postprocess_plan(L, pr.input_size, pr.original_size) is not None
 
-    def _keep_batch(self, masks, iou, low, points: list, iou_thresh: float, stab_thresh: float, stab_off: float, keep_lists: dict):
+    def _keep_batch(self, masks, iou, low, points: list, iou_thresh: float, stab_thresh: float, stab_off: float, keep_lists: dict,
+                    defer: bool = False):
         """masks [B, C, H, W] logits (or None: they are evaluated from ``low`` [B, C, L, L] on the fly): one statistics
         launch, the two filters on the host, survivors kept as {0,1} floats on the GPU.  ``points`` holds the prompt
-        points of every batch row."""
+        points of every batch row.  ``defer`` (only with masks None, and only when no other prediction follows before
+        the crop's NMS): nothing is made of the survivors yet - their plane numbers go to keep_lists["planes"] and
+        ``low`` with its plan to keep_lists["deferred"]; _process_crop makes the masks of what the NMS keeps."""
         pr, dev = self.predictor, self.predictor.device
         nm, n = low.shape[1], low.shape[0] * low.shape[1]
         iou = iou.flatten(0, 1)
@@ -93,7 +96,7 @@ class SamAutomaticMaskGenerator:
         plan, all_bits = None, None
         if masks is None:                                             # logits evaluated from ``low`` inside the kernels
             plan = pr.model.postprocess_plan(low.shape[-1], pr.input_size, pr.original_size)
-            if iou_thresh <= 0.0 and stab_thresh <= 0.0:             # no filter: every mask is kept, its 0 / 1 form comes out of the same pass
+            if iou_thresh <= 0.0 and stab_thresh <= 0.0 and not defer:    # no filter: every mask is kept, its 0 / 1 form comes out of the same pass
                 all_bits = torch.empty(n, int(pr.original_size[0]), int(pr.original_size[1]), dtype=torch.float32, device=dev)
             ops.resample_mask_stats(low, *plan, pr.model.mask_threshold, stab_off, stats, bits=all_bits)
         else:
@@ -108,6 +111,14 @@ class SamAutomaticMaskGenerator:
             keep &= stab >= stab_thresh
         idx = torch.nonzero(keep).flatten()
         if idx.numel() == 0:
+            return
+        keep_lists["iou"].append(iou_h[idx])
+        keep_lists["stab"].append(stab[idx])
+        keep_lists["boxes"].append(st[idx, 2:6].float())
+        keep_lists["points"].extend(points[int(i) // nm] for i in idx.tolist())      # rows repeat once per output mask
+        if defer and masks is None:
+            keep_lists["planes"] = idx
+            keep_lists["deferred"] = (low, plan)
             return
         sel = idx.to(dev)
         if all_bits is not None:
@@ -124,13 +135,9 @@ class SamAutomaticMaskGenerator:
             ops.threshold_masks(kept, pr.model.mask_threshold, binm)
             low_kept = low.flatten(0, 1)[sel]
         keep_lists["masks"].append(binm)
-        keep_lists["iou"].append(iou_h[idx])
-        keep_lists["stab"].append(stab[idx])
-        keep_lists["boxes"].append(st[idx, 2:6].float())
-        keep_lists["points"].extend(points[int(i) // nm] for i in idx.tolist())      # rows repeat once per output mask
         keep_lists["low"].append(low_kept)
 
-    def _process_batch(self, points: np.ndarray, im_size, keep_lists: dict):
+    def _process_batch(self, points: np.ndarray, im_size, keep_lists: dict, defer: bool = False):
         pr, dev = self.predictor, self.predictor.device
         tp = torch.as_tensor(pr.transform.apply_coords(points, im_size), dtype=torch.float32, device=dev)
         labels = torch.ones(tp.shape[0], 1, dtype=torch.int32, device=dev)
@@ -138,7 +145,7 @@ class SamAutomaticMaskGenerator:
                                            upscale=not self._fused_post())
         masks, iou, low = self._pick_layers(self.output_layer, masks, iou, low)
         self._keep_batch(masks, iou, low, [[p] for p in points.tolist()], self.pred_iou_thresh, self.stability_score_thresh,
-                         self.stability_score_offset, keep_lists)
+                         self.stability_score_offset, keep_lists, defer=defer and masks is None)
 
     def _process_sel_batch(self, im_size, point_coords: np.ndarray, point_labels: np.ndarray, keep_lists: dict, box=None,
                            mask_input=None):
@@ -176,8 +183,11 @@ class SamAutomaticMaskGenerator:
         lists = dict(masks=[], iou=[], stab=[], boxes=[], points=[], low=[])
         if self.dense_pred:
             pts_all = self.point_grids[layer] * np.array([[cw, ch]], dtype=np.float64)
+            # One decoder batch and nothing after it: the NMS below needs boxes and scores only, so the 0 / 1 masks (and the
+            # copies of the low-resolution logits) are made afterwards, of what it keeps, not of every survivor of the filters.
+            single = len(pts_all) <= self.dense_points_per_launch and not (layer == 0 and select_point_coords is not None)
             for b0 in range(0, len(pts_all), self.dense_points_per_launch):
-                self._process_batch(pts_all[b0:b0 + self.dense_points_per_launch], (ch, cw), lists)
+                self._process_batch(pts_all[b0:b0 + self.dense_points_per_launch], (ch, cw), lists, defer=single)
         if layer == 0 and select_point_coords is not None:
             assert select_point_labels is not None, "select_point_labels should not be None !"
             for coords, labels in zip(select_point_coords, select_point_labels):     # one array per prompt size
@@ -189,13 +199,21 @@ class SamAutomaticMaskGenerator:
         if not lists["iou"]:
             return None
         points = lists.pop("points")
-        cat = {k: (v[0] if len(v) == 1 else torch.cat(v, dim=0)) for k, v in lists.items()}      # (cat copies even a single tensor)
+        deferred, planes = lists.pop("deferred", None), lists.pop("planes", None)
+        cat = {k: (v[0] if len(v) == 1 else torch.cat(v, dim=0)) for k, v in lists.items() if v}      # (cat copies even a single tensor)
         ok = ~is_box_near_crop_edge(cat["boxes"], crop_box, [0, 0, ow, oh])           # lines 443-446
         order = ops.box_nms_host(cat["boxes"][ok], cat["iou"][ok], self.box_nms_thresh)
         keep = torch.nonzero(ok).flatten()[order]
         if keep.numel() == 0:
             return None
         out = {k: v[keep.to(v.device)] for k, v in cat.items()}
+        if deferred is not None:
+            low, plan = deferred
+            pk, dev = planes[keep], low.device
+            out["masks"] = torch.empty(pk.numel(), ch, cw, dtype=torch.float32, device=dev)
+            ops.resample_threshold(low, pk.to(torch.int32).to(dev), *plan, self.predictor.model.mask_threshold, out["masks"])
+            pkd = pk.to(dev)
+            out["low"] = low[pkd // low.shape[1], pkd % low.shape[1]]
         out["points"] = [[[x + x0, y + y0] for x, y in points[i]] for i in keep.tolist()]
         out["boxes"] = out["boxes"] + torch.tensor([[x0, y0, x0, y0]], dtype=out["boxes"].dtype)
         if (ch, cw) != (oh, ow):                                                      # masks of a crop, zero outside it
