@@ -323,6 +323,12 @@ extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ld
     MARS_CHECK((int64_t)nb * H <= 65535, "sam_attn: too many (image, head) pairs for one launch");
     const float c2 = scale * 1.4426950408889634f;
     if (hdp == 64) return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
-    if (hdp == 80) return launch<80, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+    if (hdp == 80) {
+        // long rows (the global blocks): two 16-query blocks a wave share every K / V tile the workgroup brings in
+        // (the one-key-row-per-tile form only: the general bias lookup does not fit beside two blocks' accumulators)
+        if (T >= 1024 && Wk == KT && T == Hk * Wk && ((uintptr_t)rel_w % 16) == 0)
+            return launch<80, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+        return launch<80, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+    }
     return launch<128, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
 }
