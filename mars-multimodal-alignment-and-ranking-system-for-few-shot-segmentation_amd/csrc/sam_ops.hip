@@ -2,6 +2,7 @@
 // row gathers (window partition / un-partition, 3x3 neighbourhoods, pixel shuffles), the decomposed
 // relative-position bias, a row softmax with that bias, the random-Fourier position code, and the
 // per-mask statistics of the automatic mask generator.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "../../include/mars_hip.h"
@@ -481,9 +482,9 @@ __device__ __forceinline__ float banded_sum(const float* __restrict__ v, int str
             wk[k] = k < kmax ? w[k] : 0.f;                // (a row of the table holds kmax weights)
         }
 #pragma unroll
-        for (int k = 0; k < KT; ++k) acc = k == 0 ? x[0] * wk[0] : acc + x[k] * wk[k];
+        for (int k = 0; k < KT; ++k) acc = k == 0 ? x[0] * wk[0] : __builtin_fmaf(x[k], wk[k], acc);
     } else {
-        for (int k = 0; k < ms; ++k) acc = k == 0 ? v[m0 * stride] * w[0] : acc + v[(m0 + k) * stride] * w[k];
+        for (int k = 0; k < ms; ++k) acc = k == 0 ? v[m0 * stride] * w[0] : __builtin_fmaf(v[(m0 + k) * stride], w[k], acc);
     }
     return acc;
 }
@@ -572,6 +573,162 @@ __global__ __launch_bounds__(256) void resample_bands_kernel(const float* __rest
     }
 }
 
+// The statistics again, for tables of at most KT taps and images at most blockDim.x CPT wide: a thread owns CPT columns of the
+// image and walks down the plane once.  Per source row it forms the row's x-resampled value for its columns (the x table
+// of a column sits in registers) and keeps the last KT of them in registers; an output row y whose first source row is
+// ylo[y] is due when the window holds rows ylo[y] .. ylo[y] + KT - 1 (rows past the last repeat it, as the clamped
+// index of banded_sum does; weights past a row's size are zero in the table).  Against the band form no x-resampled
+// value goes through LDS, no source row is brought twice, and the tables are read once a plane, not once a band: LDS
+// holds the y table and a chunk of R source rows (each followed by KT copies of its last value, so column reads need no
+// clamp), the next chunk on its way in registers while the current one is worked on.  Same sums in the same order as
+// banded_sum: the same values.  A y table whose first rows do not grow with y is still served (the window starts over
+// at such a row), at the price of rows brought again.
+template <int KT, int CPT>
+__global__ __launch_bounds__(256) void resample_stats_columns_kernel(const float* __restrict__ low, int64_t stride_b, int64_t stride_c, int nm, int L,
+                                                                     int H, int W, AxisTable tx, AxisTable ty, int R, float thr, float off,
+                                                                     int32_t* __restrict__ stats, float* __restrict__ out) {
+    extern __shared__ float cols_lds[];
+    const int Ls = L + KT, L4 = L >> 2;
+    float* yw = cols_lds;                                // [H][KT]
+    float* srow = yw + (size_t)H * KT;                   // [R][Ls]
+    int* ylo = (int*)(srow + (size_t)R * Ls);            // [H]
+    __shared__ int sh[6][4];
+    const int plane = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;        // NT: whole waves, at most 256
+    const float* src = low + (int64_t)(plane / nm) * stride_b + (int64_t)(plane % nm) * stride_c;
+    for (int i = tid; i < H; i += NT) {
+        ylo[i] = ty.lo[i];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) yw[i * KT + k] = k < ty.kmax ? ty.w[(int64_t)i * ty.kmax + k] : 0.f;
+    }
+    int m0x[CPT];
+    float wx[CPT][KT], win[CPT][KT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int xx = min(tid + NT * j, W - 1);
+        m0x[j] = min(max(tx.lo[xx], 0), L - 1);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            wx[j][k] = k < tx.kmax ? tx.w[(int64_t)xx * tx.kmax + k] : 0.f;
+            win[j][k] = 0.f;
+        }
+    }
+    // source rows [cs, ce) are in LDS; rows [ps, ps + R) are on their way in pf (a thread's 16-byte pieces tid, tid + NT, ...)
+    constexpr int PF = 4;                                // R L <= NT PF 4 values
+    int cs = 0, ce = 0, ps = 0;
+    f32x4 pf[PF];
+    auto fetch = [&](int start) {
+        ps = start;
+        const int n4 = min(R, L - start) * L4;
+        const f32x4* sp = (const f32x4*)(src + (int64_t)start * L);
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int i = tid + NT * p;
+            pf[p] = i < n4 ? sp[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+        __syncthreads();                                  // (everybody is done with the rows in LDS)
+        const int n4 = min(R, L - ps) * L4;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int i = tid + NT * p;
+            if (i < n4) {
+                const int row = i / L4, c4 = i - row * L4;
+                ((f32x4*)(srow + row * Ls))[c4] = pf[p];
+                if (c4 == L4 - 1) {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) srow[row * Ls + L + k] = pf[p][3];
+                }
+            }
+        }
+        cs = ps;
+        ce = min(ps + R, L);
+        __syncthreads();
+        if (ce < L) fetch(ce);
+    };
+    fetch(0);
+    __syncthreads();                                      // the y table
+    const float t_hi = thr + off, t_lo = thr - off;
+    int hi = 0, lo = 0, y0 = H, y1 = -1;                  // (wave-uniform)
+    unsigned long long hit[CPT] = {}, okm[CPT];           // okm: the lanes whose column j is inside the image
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) okm[j] = __builtin_amdgcn_ballot_w64(tid + NT * j < W);
+    int r = -1;                                           // the window holds rows r - KT + 1 .. r
+    for (int y = 0; y < H; ++y) {
+        const int l0 = min(max(ylo[y], 0), L - 1), top = l0 + KT - 1;
+        if (top < r || l0 > r + 1) r = l0 - 1;           // rows skipped, or a table that goes back: the window starts over
+        while (r < top) {
+            ++r;
+            const int rr = min(r, L - 1);
+            if (rr < cs || rr >= ce) {                   // (uniform: r depends on y alone)
+                if (ps != rr) fetch(rr);
+                commit();
+            }
+            const float* sp = srow + (rr - cs) * Ls;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                float v[KT];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) v[k] = sp[m0x[j] + k];
+                float acc = v[0] * wx[j][0];
+#pragma unroll
+                for (int k = 1; k < KT; ++k) acc = __builtin_fmaf(v[k], wx[j][k], acc);
+#pragma unroll
+                for (int k = 0; k + 1 < KT; ++k) win[j][k] = win[j][k + 1];
+                win[j][KT - 1] = acc;
+            }
+        }
+        float wy[KT];
+#pragma unroll
+        for (int k4 = 0; k4 < KT / 4; ++k4) {
+            const f32x4 w4 = ((const f32x4*)yw)[y * (KT / 4) + k4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wy[4 * k4 + k] = w4[k];
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int x = tid + NT * j;
+            const bool ok = x < W;
+            float acc = win[j][0] * wy[0];
+#pragma unroll
+            for (int k = 1; k < KT; ++k) acc = __builtin_fmaf(win[j][k], wy[k], acc);
+            // counts and the box on the wave's lane masks: scalar work beside the sums
+            const unsigned long long mh = __builtin_amdgcn_ballot_w64(acc > t_hi) & okm[j], ml = __builtin_amdgcn_ballot_w64(acc > t_lo) & okm[j],
+                                     mi = __builtin_amdgcn_ballot_w64(acc > thr) & okm[j];
+            hi += __popcll(mh);
+            lo += __popcll(ml);
+            hit[j] |= mi;
+            if (mi) { y0 = min(y0, y); y1 = y; }
+            if (out && ok) out[((int64_t)plane * H + y) * W + x] = acc > thr ? 1.f : 0.f;
+        }
+    }
+    // hi, lo, y0 and y1 are the wave's; the columns a lane's outputs were set in give x0 and x1
+    int x0 = W, x1 = -1;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+        if ((hit[j] >> (tid & 63)) & 1) { x0 = min(x0, tid + NT * j); x1 = max(x1, tid + NT * j); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64));
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) { sh[0][wave] = hi; sh[1][wave] = lo; sh[2][wave] = x0; sh[3][wave] = y0; sh[4][wave] = x1; sh[5][wave] = y1; }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t* o = stats + (int64_t)plane * 6;
+        int a = 0, b = 0, bx0 = W, by0 = H, bx1 = -1, by1 = -1;
+        for (int w = 0; w < NT / 64; ++w) {
+            a += sh[0][w]; b += sh[1][w];
+            bx0 = min(bx0, sh[2][w]); by0 = min(by0, sh[3][w]); bx1 = max(bx1, sh[4][w]); by1 = max(by1, sh[5][w]);
+        }
+        o[0] = a;
+        o[1] = b;
+        const bool empty = bx1 < bx0 || by1 < by0;      // an empty mask has the box [0, 0, 0, 0]
+        o[2] = empty ? 0 : bx0; o[3] = empty ? 0 : by0; o[4] = empty ? 0 : bx1; o[5] = empty ? 0 : by1;
+    }
+}
+
 int check_bands(const char* what, const float* low, int nm, int L, int H, int W, const MarsAxisTable* tx, const MarsAxisTable* ty, int band,
                 int max_rows) {
     MARS_CHECK(low && tx && ty && tx->lo && tx->size && tx->w && ty->lo && ty->size && ty->w, "%s: null pointer", what);
@@ -592,6 +749,27 @@ extern "C" int marship_resample_mask_stats(const float* low, int64_t stride_b, i
     const AxisTable ax = {tx->lo, tx->size, tx->w, tx->kmax}, ay = {ty->lo, ty->size, ty->w, ty->kmax};
     const size_t shm = (size_t)max_rows * (W + L) * sizeof(float);
     const int kt = ax.kmax <= 4 && ay.kmax <= 4 ? 4 : ax.kmax <= 8 && ay.kmax <= 8 ? 8 : 0;
+    // short tables, images up to 1024 wide, planes whose rows are whole 16-byte pieces: a thread walks its columns down
+    // the plane (MARS_RESAMPLE_COLUMNS=0, read at every call: the band form, for comparisons)
+    const char* env = getenv("MARS_RESAMPLE_COLUMNS");
+    if (kt != 0 && W <= 1024 && L % 4 == 0 && L <= 4096 && ((uintptr_t)low % 16) == 0 && stride_b % 4 == 0 && stride_c % 4 == 0 && !(env && env[0] == '0')) {
+        // columns a thread at 256 threads a workgroup, then only as many whole waves as those columns need.  (Six such
+        // workgroups fit a CU; wider ones with fewer columns a thread left fewer planes in flight and were slower: 640
+        // columns as 2 x 320 threads 1.2 ms for 3072 planes, 3 x 256 0.9, 4 x 192 1.0.)
+        const int cpt = (W + 255) / 256, nt = ((W + cpt - 1) / cpt + 63) / 64 * 64;
+        const int R = 16 * nt / L < 16 ? (16 * nt / L < 1 ? 1 : 16 * nt / L) : 16;       // R L / 4 <= 4 nt pieces
+        const size_t lds = ((size_t)R * (L + kt) + (size_t)H * (kt + 1)) * sizeof(float);
+        if ((int64_t)R * L <= 16 * nt && lds <= 64 * 1024) {
+#define MARS_COLS(KT, CPT)                                                                                                                    \
+    hipLaunchKernelGGL((resample_stats_columns_kernel<KT, CPT>), dim3((unsigned)n), dim3(nt), lds, (hipStream_t)stream, low, stride_b, stride_c, \
+                       nm, L, H, W, ax, ay, R, thr, off, stats, bits)
+            if (kt == 4) { if (cpt == 1) MARS_COLS(4, 1); else if (cpt == 2) MARS_COLS(4, 2); else if (cpt == 3) MARS_COLS(4, 3); else MARS_COLS(4, 4); }
+            else { if (cpt == 1) MARS_COLS(8, 1); else if (cpt == 2) MARS_COLS(8, 2); else if (cpt == 3) MARS_COLS(8, 3); else MARS_COLS(8, 4); }
+#undef MARS_COLS
+            MARS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define MARS_BANDS(KT)                                                                                                                       \
     hipLaunchKernelGGL((resample_bands_kernel<true, KT>), dim3((unsigned)n), dim3(256), shm, (hipStream_t)stream, low, stride_b, stride_c, nm,    \
                        (const int32_t*)nullptr, L, H, W, ax, ay, band, max_rows, thr, off, stats, bits)

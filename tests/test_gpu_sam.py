@@ -443,15 +443,21 @@ def test_fused_upscaling_agrees_with_stagewise_form(pkg, monkeypatch):
     assert float(((m1 > 0) != (m0 > 0)).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("columns", ["1", "0", "flipped"])
 @pytest.mark.parametrize("L,S,inp,orig", [(256, 1024, (768, 1024), (480, 640)), (32, 128, (128, 96), (333, 250)), (64, 256, (171, 256), (100, 150)),
-                                           (256, 1024, (1024, 683), (1500, 1000))])
-def test_on_the_fly_postprocess_equals_the_stored_form(pkg, L, S, inp, orig):
+                                           (256, 1024, (1024, 683), (1500, 1000)), (30, 120, (120, 90), (77, 55))])
+def test_on_the_fly_postprocess_equals_the_stored_form(pkg, monkeypatch, L, S, inp, orig, columns):
     """Statistics and 0 / 1 masks evaluated from the low-resolution logits inside the kernels == postprocess_masks
-    (two stored passes) followed by mask_stats / threshold_masks, bit for bit; a strided view of four planes a prompt."""
+    (two stored passes) followed by mask_stats / threshold_masks, bit for bit; a strided view of four planes a prompt.
+    The statistics in both forms (a thread walking its columns down the plane where the shape allows it / a band of
+    output rows at a time), and on a y table in reverse order (output rows bottom up: the walk starts over at every row)."""
     ops, rs = pkg.ops, pkg.resample
     dev = torch.device("cuda")
     oh, ow = orig
+    monkeypatch.setenv("MARS_RESAMPLE_COLUMNS", "0" if columns == "0" else "1")
     th_h, tw_h = rs.sam_postprocess_table(L, S, inp[0], oh), rs.sam_postprocess_table(L, S, inp[1], ow)
+    if columns == "flipped":
+        th_h = tuple(np.ascontiguousarray(a[::-1]) for a in th_h)
     up = lambda t: tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in t)
     th, tw = up(th_h), up(tw_h)
     band, rows = rs.band_plan(th_h, L, ow)
