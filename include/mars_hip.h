@@ -291,7 +291,8 @@ int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd
  * bias of :357-359): O[b*T+t, head*hdp+d] = sum_k softmax_k(scale q.k + rel_h[.., k / Wk] + rel_w[.., k % Wk]) v[k, d]
  * for bf16 qkv rows (row stride ld; q, k, v of head h at columns h*hdp, (H+h)*hdp, (2H+h)*hdp), hdp 64 or 128
  * (zero-padded head dims give zero outputs) or 80 (the ViT-H head as it is), rel_h [nb*H, T, Hk], rel_w [nb*H, T, Wk] as marship_relpos_bias
- * leaves them.  Replaces the score product, marship_softmax_bias_rows and the P.V product for bf16 towers. */
+ * leaves them.  Replaces the score product, marship_softmax_bias_rows and the P.V product for bf16 towers.
+ * T <= 65536, Wk <= 65535, scale > 0. */
 int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
                      int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream);
 /* P[row, k] = softmax_k(S[row, k] + rel_h[row, k / Wk] + rel_w[row, k % Wk]) (image_encoder.py:357-359,236;

@@ -18,6 +18,7 @@
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -43,22 +44,33 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 a, f32x4 b) {
 // power-of-two row); QB: 16-query blocks per wave; four waves per workgroup.  K / V tiles of 64 keys
 // are double buffered and filled by LDS-DMA; a tile's last fragments are in registers before the fill of the next
 // tile starts (hipcc would otherwise drain the DMAs in front of every LDS read that follows one).
-// ALLKV (T <= 4 tiles: the 14 x 14 windows): one workgroup of NW waves per (image, head); all of K and V is brought into
+// ALLKV (64 < T <= 224: the 14 x 14 windows): one workgroup of NW waves per (image, head); all of K and V is brought into
 // LDS by one burst of fills and one barrier, then every wave walks its 16-query blocks over the resident tiles.  With
 // four 64-query workgroups per (window, head), each re-filling the same 196 keys tile by tile behind a barrier, the
 // windowed blocks spent their time waiting: four dependent fill latencies for a few hundred matrix instructions.
 template <int HD, int QB, bool ROWTILE, int NW = 4, bool ALLKV = false>
-__global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const __bf16* __restrict__ qkv, int64_t ld, __bf16* __restrict__ O,
+__global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn_kernel(const __bf16* __restrict__ qkv, int64_t ld, __bf16* __restrict__ O,
                                                           int64_t ldo, const float* __restrict__ rel_h,
                                                           const float* __restrict__ rel_w, int T, int H, int Hk, int Wk,
-                                                          float c2) {
+                                                          float c2, unsigned wk_magic) {
     constexpr int ROWB = HD * 2, KS = (HD + 31) / 32, DM = HD / 16, QPB = NW * QB * 16;
     constexpr bool LINEAR = (1024 % ROWB) != 0;    // rows that do not tile a 1-KiB fill piece: no swizzle
     static_assert(!ALLKV || QB == 1, "the resident form walks one 16-query block a wave at a time");
     constexpr int PPO = KT * ROWB / 1024;          // 1-KiB DMA pieces per operand tile
     constexpr int LPR = ROWB / 16;                 // 16-byte chunks (lanes of a fill) per key row
     static_assert(KT * ROWB % 1024 == 0, "an operand tile is a whole number of fill pieces");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[ALLKV ? 4 : 2][2][KT * ROWB];      // [buf][K|V]
+    // [buf][K|V] tiles of TB bytes; the resident form: three whole tiles and the first 32 rows of a fourth (T <= 224), K and V each,
+    // 70 KB at 80 dims: two workgroups fit a CU
+    constexpr int TB = KT * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ALLKV ? 7 * TB : 4 * TB];
+    auto tile = [&](int buf, int opnd) -> unsigned char* { return lds + buf * 2 * TB + opnd * ((ALLKV && buf == 3) ? TB / 2 : TB); };
+    // The resident form adds the bias on the matrix pipe when a query's two bias rows fit one K step (Hk + Wk <= 32):
+    // bias[key][q] = sum_i E[key][i] R[i][q] with R[., q] = (rel_h[q][0 .. Hk), rel_w[q][0 .. Wk), 0 ...) and E[key] the
+    // indicator of the two entries key = (kh, kw) picks.  A lane makes its eight entries of E from the key's (kh, kw)
+    // with a few integer instructions; R is the query block's B operand, as three bf16 terms whose sum is the f32 value
+    // (8 + 8 + 8 mantissa bits).  That replaces 32 gathered loads per query block and tile, which the texture path
+    // serves a few lanes a clock: they were most of a block's time whatever the occupancy.
+    const bool bias_mm = ALLKV && Hk + Wk <= 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r16 = lane & 15;
@@ -72,6 +84,7 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
     bf16x8 qf[QB][KS];
     const float* hrow[QB];                         // this lane's rows of the bias terms
     const float* wrow[QB];
+    bf16x8 rb[ALLKV ? 3 : 1];                      // (bias_mm) R of the query block: entries 8 g .. 8 g + 7, in units of c2
     auto load_queries = [&]() {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -86,6 +99,25 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
             hrow[qb] = rel_h + qr * Hk;
             wrow[qb] = rel_w + qr * Wk;
         }
+        if constexpr (ALLKV) {
+            if (bias_mm) {
+                const float unit = LOG2E / c2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = 8 * g + e;
+                    float v = 0.f;
+                    if (i < Hk) v = hrow[0][i];
+                    else if (i < Hk + Wk) v = wrow[0][i - Hk];
+                    v *= unit;
+                    const __bf16 hi = (__bf16)v;
+                    const float r1 = v - (float)hi;
+                    const __bf16 mid = (__bf16)r1;
+                    rb[0][e] = hi;
+                    rb[1][e] = mid;
+                    rb[2][e] = (__bf16)(r1 - (float)mid);
+                }
+            }
+        }
     };
     load_queries();
 
@@ -93,11 +125,12 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
 #pragma unroll
         for (int p = wave; p < 2 * PPO; p += NW) {       // fill pieces of 1 KiB: 64 consecutive chunks of an operand tile
             const int opnd = p / PPO, pp = p % PPO;
+            if (ALLKV && buf == 3 && pp >= PPO / 2) continue;         // (the fourth resident tile holds 32 rows)
             const int c = pp * 64 + lane, row = c / LPR, slot = c - row * LPR;
             const int chunk = LINEAR ? slot : slot ^ ((row >> 1) & 7);
             const int key = min(t * KT + row, T - 1);
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (1 + opnd) * opnd_b + (int64_t)key * row_b + chunk * 16),
-                                             (lds_ptr_t)(&lds[buf][opnd][pp * 1024]), 16, 0, 0);
+                                             (lds_ptr_t)(tile(buf, opnd) + pp * 1024), 16, 0, 0);
         }
     };
 
@@ -122,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
     const int vq = r16 >> 2, vp = r16 & 3, vsw = (2 * g + (vq >> 1)) & 7;    // of V rows 32 s + 4 g + vq (+ 16)
 
     auto read_k = [&](int buf) {
-        const unsigned char* kt = &lds[buf][0][0];
+        const unsigned char* kt = tile(buf, 0);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -133,8 +166,30 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
                     kf[f][ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt + (16 * f + r16) * ROWB + ((LINEAR ? 4 * ks + g : (4 * ks + g) ^ ksw) << 4)));
             }
     };
+    // (the resident form reads a fragment when it is needed: with everything of a tile in registers at once a wave needs
+    // more than the 128 registers that let two workgroups share a CU)
+    auto read_k_frag = [&](int buf, int f, bf16x8 (&dst)[KS]) {
+        const unsigned char* kt = tile(buf, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            dst[ks] = bf16x8{};
+            if (4 * ks + g < LPR)
+                dst[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(kt + (16 * f + r16) * ROWB + ((LINEAR ? 4 * ks + g : (4 * ks + g) ^ ksw) << 4)));
+        }
+    };
+    auto read_v_half = [&](int buf, int sh, bf16x8 (&dst)[DM]) {
+        const unsigned char* vt = tile(buf, 1);
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            const int off = (4 * g + vq) * ROWB + ((LINEAR ? 2 * m + (vp >> 1) : (2 * m + (vp >> 1)) ^ vsw) << 4) + 8 * (vp & 1);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vt + off + sh * 32 * ROWB));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vt + off + sh * 32 * ROWB + 16 * ROWB));
+            const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            dst[m] = __builtin_bit_cast(bf16x8, r);
+        }
+    };
     auto read_v = [&](int buf) {
-        const unsigned char* vt = &lds[buf][1][0];
+        const unsigned char* vt = tile(buf, 1);
 #pragma unroll
         for (int m = 0; m < DM; ++m) {
             // V^T[d = 16 m + 4 vp ..][keys]: byte column 32 m + 8 vp of rows 32 s + 4 g + vq and + 16
@@ -163,17 +218,33 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
             for (int f = 0; f < 4; ++f) {
                 if (!MASKED || f < nfrag) {
                     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (ALLKV) read_k_frag(t, f, kf[f & 1]);           // (tile t lives in buffer t)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][ks], qf[qb][ks], acc, 0, 0, 0);
+                    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ALLKV ? (f & 1) : f][ks], qf[qb][ks], acc, 0, 0, 0);
                     if constexpr (ROWTILE) {
                         const f32x4 wv = *(const f32x4*)(wrow[qb] + 16 * f + 4 * g);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[j] = fmaf(acc[j], c2, fmaf(wv[j], LOG2E, hval));
+                    } else if (ALLKV && bias_mm) {
+                        // E of key 64 t + 16 f + r16, entries 8 g .. 8 g + 7: bit e of m is set where the entry is one
+                        const int key = min(t * KT + 16 * f + r16, T - 1);
+                        const int kh = Wk == 1 ? key : (int)__umulhi((unsigned)key, wk_magic), kw = key - kh * Wk;
+                        const unsigned ia = (unsigned)(kh - 8 * g), ib = (unsigned)(Hk + kw - 8 * g);
+                        const unsigned m = (ia < 8u ? 1u << ia : 0u) | (ib < 8u ? 1u << ib : 0u);
+                        v4u32 ew;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) ew[d] = ((m >> (2 * d)) & 1u) * 0x3f80u + ((m >> (2 * d + 1)) & 1u) * 0x3f800000u;
+                        const bf16x8 ef = __builtin_bit_cast(bf16x8, ew);
+#pragma unroll
+                        for (int i = 0; i < (ALLKV ? 3 : 1); ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, rb[i], acc, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] *= c2;
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
+                            // key / Wk as a multiply: wk_magic = ceil(2^32 / Wk), exact while key Wk < 2^32 (the host checks T)
                             const int key = min(t * KT + 16 * f + 4 * g + j, T - 1);
-                            const int kh = key / Wk, kw = key - kh * Wk;
+                            const int kh = Wk == 1 ? key : (int)__umulhi((unsigned)key, wk_magic), kw = key - kh * Wk;
                             acc[j] = fmaf(acc[j], c2, (hrow[qb][kh] + wrow[qb][kw]) * LOG2E);
                         }
                     }
@@ -214,6 +285,20 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
     };
     auto accumulate = [&](int t) {
         const bool second = (T - t * KT) > 32;                   // keys beyond the first 32 of the tile
+        if constexpr (ALLKV) {
+            bf16x8 vh[DM];
+            read_v_half(t, 0, vh);
+#pragma unroll
+            for (int m = 0; m < DM; ++m) o[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[m], pr[0][0], o[0][m], 0, 0, 0);
+            o[0][DM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pr[0][0], o[0][DM], 0, 0, 0);
+            if (second) {
+                read_v_half(t, 1, vh);
+#pragma unroll
+                for (int m = 0; m < DM; ++m) o[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[m], pr[0][1], o[0][m], 0, 0, 0);
+                o[0][DM] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pr[0][1], o[0][DM], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
@@ -253,11 +338,8 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
         for (; q0 < T; q0 += NW * 16) {
             if (q0 != wave * 16) { load_queries(); reset_state(); }
             for (int t = 0; t < nt; ++t) {
-                read_k(t);
                 if (t * KT + KT > T) scores(t, std::true_type{});
                 else scores(t, std::false_type{});
-                read_v(t);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 accumulate(t);
             }
             store_queries();
@@ -291,11 +373,12 @@ __global__ __launch_bounds__(NW * 64, ALLKV ? 1 : 2) void sam_attn_kernel(const 
 template <int HD, int QB>
 int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w, int nb, int T,
            int H, int Hk, int Wk, float c2, hipStream_t s) {
+    const unsigned wk_magic = Wk > 1 ? (unsigned)((0x100000000ull + (unsigned)Wk - 1) / (unsigned)Wk) : 0u;      // (a grid one token wide does not use it)
     if constexpr (QB == 1) {
         // every key of a small token grid (the windows) resident in LDS: one workgroup of eight waves per (image, head)
-        if (T <= 4 * KT && T > KT && !(Wk == KT && T == Hk * Wk)) {
+        if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) {
             hipLaunchKernelGGL((sam_attn_kernel<HD, 1, false, 8, true>), dim3(1, nb * H), dim3(512), 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h,
-                               rel_w, T, H, Hk, Wk, c2);
+                               rel_w, T, H, Hk, Wk, c2, wk_magic);
             MARS_LAUNCH_CHECK();
             return 0;
         }
@@ -304,9 +387,9 @@ int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h
     dim3 grid((T + QPB - 1) / QPB, nb * H), block(256);
     // one key row per tile: no division, and whole 16-byte loads of rel_w (rows of 64 floats are 16-byte aligned)
     if (Wk == KT && T == Hk * Wk && ((uintptr_t)rel_w % 16) == 0)
-        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, true>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2);
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, true>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic);
     else
-        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, false>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2);
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, false>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic);
     MARS_LAUNCH_CHECK();
     return 0;
 }
@@ -321,8 +404,14 @@ extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ld
     MARS_CHECK(ld >= 3 * (int64_t)H * hdp && ld % 8 == 0 && ldo >= (int64_t)H * hdp && ldo % 4 == 0, "sam_attn: row strides");
     MARS_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)O % 8) == 0, "sam_attn: alignment");
     MARS_CHECK((int64_t)nb * H <= 65535, "sam_attn: too many (image, head) pairs for one launch");
+    MARS_CHECK(scale > 0.f && scale < 1e6f, "sam_attn: the score scale must be positive and finite");
+    MARS_CHECK(T <= 65536 && Wk <= 65535, "sam_attn: token grids up to 65536 tokens (T=%d, Wk=%d)", T, Wk);
     const float c2 = scale * 1.4426950408889634f;
-    if (hdp == 64) return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+    if (hdp == 64) {
+        // (the windows: every key resident, one 16-query block a wave at a time)
+        if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) return launch<64, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+        return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+    }
     if (hdp == 80) {
         // long rows (the global blocks): two 16-query blocks a wave share every K / V tile the workgroup brings in
         // (the one-key-row-per-tile form only: the general bias lookup does not fit beside two blocks' accumulators)

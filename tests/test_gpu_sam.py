@@ -367,10 +367,13 @@ def test_generator_small_regions_and_coco_rle(pkg):
                                                   (2, 14, 14, 2, 80, 128), (1, 10, 10, 1, 64, 64), (2, 5, 13, 2, 48, 64),
                                                   (3, 16, 16, 2, 80, 128), (1, 9, 9, 1, 96, 128), (2, 8, 8, 1, 80, 128), (1, 13, 5, 3, 80, 128),
                                                   (1, 64, 64, 2, 80, 80), (2, 14, 14, 3, 80, 80), (3, 16, 16, 2, 80, 80), (1, 9, 9, 1, 80, 80),
-                                                  (2, 8, 8, 1, 80, 80), (1, 13, 5, 3, 80, 80), (1, 20, 20, 2, 80, 80)])
+                                                  (2, 8, 8, 1, 80, 80), (1, 13, 5, 3, 80, 80), (1, 20, 20, 2, 80, 80),
+                                                  (1, 4, 40, 2, 80, 80), (1, 2, 100, 1, 64, 64), (1, 100, 1, 1, 64, 64), (2, 7, 25, 2, 64, 64)])
 def test_fused_attention_with_relpos_bias(pkg, nb, gh, gw, H, hd, hdp):
     """marship_sam_attn against softmax(scale q.k + rel_h + rel_w) v in f64 on the same bf16 operands: global
-    blocks of a 1024-pixel image (one key row per tile), windows, ragged last tiles, padded head dims."""
+    blocks of a 1024-pixel image (one key row per tile), windows (every key resident; the bias as a matrix product when
+    a query's two bias rows have at most 32 entries together, looked up per score otherwise), ragged last tiles, padded
+    head dims, grids one token wide."""
     ops = pkg.ops
     T = gh * gw
     g = torch.Generator().manual_seed(nb * 1000 + T + hdp)
