@@ -115,6 +115,73 @@ __global__ __launch_bounds__(256) void relpos_bias_kernel(const T* __restrict__ 
     }
 }
 
+// The same terms for small token grids (the 14 x 14 windows; sides and tables up to 16, bf16 queries) on the matrix
+// pipe: a wave owns one table slice - the queries of grid row qh against Rh[qh], or of grid column qw against Rw[qw] -
+// which is one 16 x 16 tile of v_mfma_f32_16x16x32_bf16: table rows on M, queries on N, head dims on K.  The queries
+// are the B operand as they are stored; the f32 table is the A operand as three bf16 terms that add up to its value
+// (8 + 8 + 8 mantissa bits), accumulated in f32.  With one workgroup per slice on the vector ALU (above) a window
+// layer launched 11200 workgroups of which a fifth of the threads had work.
+__global__ __launch_bounds__(256) void relpos_bias_mma_kernel(const __bf16* __restrict__ qkv, int64_t ld, int Tn, int H, int hd, int hdp, int gw,
+                                                              int Hk, int Wk, const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                              float* __restrict__ rel_h, float* __restrict__ rel_w, int64_t nslices) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    const int gh = Tn / gw, nsl = gh + gw;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nslices) return;                           // (whole waves: no barrier in this kernel)
+    const int64_t bh = wid / nsl;
+    const int sl = (int)(wid - bh * nsl);
+    const bool along_w = sl >= gh;
+    const int fixed = along_w ? sl - gh : sl;
+    const int nq = along_w ? gh : gw, nk = along_w ? Wk : Hk;
+    const int head = (int)(bh % H);
+    const int64_t b = bh / H;
+    const int n = min(r16, nq - 1);
+    const int t = along_w ? n * gw + fixed : fixed * gw + n;
+    const __bf16* qp = qkv + (b * Tn + t) * ld + (int64_t)head * hdp;
+    const float* table = (along_w ? Rw + (int64_t)fixed * Wk * hd : Rh + (int64_t)fixed * Hk * hd) + (int64_t)min(r16, nk - 1) * hd;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // every load of the slice is requested before the first product (head dims up to 128: four K steps; the same trips
+    // for every lane: a matrix instruction takes its operands from all of them)
+    bf16x8 qb[4];
+    f32x4 t0[4], t1[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int d0 = 32 * ks + 8 * g;
+        qb[ks] = bf16x8{};
+        t0[ks] = t1[ks] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (d0 < hd) {                                    // lane groups past the head's last dims add zeros
+            qb[ks] = *(const bf16x8*)(qp + d0);
+            t0[ks] = *(const f32x4*)(table + d0);
+            t1[ks] = *(const f32x4*)(table + d0 + 4);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (32 * ks >= hd) break;
+        bf16x8 a0, a1, a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = r16 < nk ? (e < 4 ? t0[ks][e & 3] : t1[ks][e & 3]) : 0.f;
+            const __bf16 hi = (__bf16)v;
+            const float r1 = v - (float)hi;
+            const __bf16 mid = (__bf16)r1;
+            a0[e] = hi;
+            a1[e] = mid;
+            a2[e] = (__bf16)(r1 - (float)mid);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qb[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qb[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, qb[ks], acc, 0, 0, 0);
+    }
+    // this lane: table rows 4 g + j against query r16
+    if (r16 < nq) {
+        float* out = (along_w ? rel_w : rel_h) + (bh * Tn + t) * nk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * g + j < nk) out[4 * g + j] = acc[j];
+    }
+}
+
 // P[row, k] = softmax_k(S[row, k] + rel_h[row, k / Wk] + rel_w[row, k % Wk]) for k < T, 0 for T <= k < ldp.
 // One workgroup per row; the biased row is kept in LDS between the three passes.
 template <typename TOUT>
@@ -815,6 +882,16 @@ extern "C" int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, in
                "relpos_bias: bad shape");
     const int gh = T / gw;
     const int nmax = gh > gw ? gh : gw, kmax = Hk > Wk ? Hk : Wk;
+    // small grids of bf16 queries: a wave per table slice on the matrix pipe (MARS_RELPOS_MMA=0, read once: the vector form)
+    static const bool mma = [] { const char* e = getenv("MARS_RELPOS_MMA"); return !(e && e[0] == '0'); }();
+    if (mma && dtype == 1 && nmax <= 16 && kmax <= 16 && hd % 8 == 0 && hd <= 128 && hdp % 8 == 0 && ld % 8 == 0 && ((uintptr_t)qkv % 16) == 0 &&
+        ((uintptr_t)Rh % 16) == 0 && ((uintptr_t)Rw % 16) == 0) {
+        const int64_t nslices = (int64_t)B * H * (gh + gw);
+        hipLaunchKernelGGL(relpos_bias_mma_kernel, dim3((unsigned)((nslices + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv, ld, T, H,
+                           hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nslices);
+        MARS_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t shm = (size_t)(nmax + kmax) * (hd + 1) * sizeof(float);
     MARS_CHECK(shm <= 64 * 1024 && (int64_t)B * H <= 65535, "relpos_bias: grid side %d, table side %d or head dim %d too large", nmax, kmax, hd);
     dim3 grid((unsigned)nmax, (unsigned)(B * H), 2), block(256);

@@ -1033,6 +1033,24 @@ def test_softmax_bias_rows_and_relpos(pkg, cuda, B, H, gw, hd, hdp):
     assert float((P[:, :T] - torch.softmax(S[:, :T], -1)).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,gh,gw,hd,hdp", [(3, 2, 14, 14, 80, 80), (2, 3, 14, 14, 64, 64), (1, 2, 16, 16, 80, 128), (2, 1, 5, 13, 48, 64),
+                                               (1, 1, 9, 9, 96, 128), (5, 4, 7, 3, 16, 64), (1, 2, 20, 20, 80, 80)])
+def test_relpos_bias_of_bf16_queries(pkg, cuda, B, H, gh, gw, hd, hdp):
+    """bf16 queries against f32 tables: grids up to 16 x 16 go through the matrix pipe (tables as three bf16 terms), larger
+    ones through the vector form; both against f64 on the same operands."""
+    ops = pkg.ops
+    T = gh * gw
+    qkv = _rand((B * T, 3 * H * hdp), 61, cuda).to(torch.bfloat16)
+    Rh, Rw = _rand((gh, gh, hd), 62, cuda), _rand((gw, gw, hd), 63, cuda)
+    rel_h = torch.full((B * H * T, gh), float("nan"), device=cuda)
+    rel_w = torch.full((B * H * T, gw), float("nan"), device=cuda)
+    ops.relpos_bias(qkv, B, T, H, hd, hdp, gw, Rh, Rw, rel_h, rel_w)
+    q = qkv[:, : H * hdp].view(B, T, H, hdp)[..., :hd].permute(0, 2, 1, 3).reshape(B * H, gh, gw, hd).double()
+    ref_h = torch.einsum("bhwc,hkc->bhwk", q, Rh.double()).reshape(-1, gh)
+    ref_w = torch.einsum("bhwc,wkc->bhwk", q, Rw.double()).reshape(-1, gw)
+    assert float((rel_h.double() - ref_h).abs().max()) < 2e-5 and float((rel_w.double() - ref_w).abs().max()) < 2e-5
+
+
 # ------------------------------------------------------------------ mask decoder: small-head attention and fused row passes
 @pytest.mark.parametrize("B,H,hd,Tq,Tk", [(5, 8, 32, 7, 7), (3, 8, 16, 7, 300), (3, 8, 16, 300, 7), (2, 4, 32, 9, 1000), (2, 4, 32, 1000, 9),
                                           (1, 1, 16, 1, 16), (70, 8, 16, 16, 4096)])
