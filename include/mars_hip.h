@@ -96,6 +96,12 @@ int marship_set_gemm_slots(int slots);
  * eps 1e-5, computed in f32).  x f32 [rows, D] with row stride x_stride; y out_dtype. */
 int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
                       int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream);
+/* The same, with row r written to row out_rows[r] of y (i32 on the device; a negative entry: not written; the caller
+ * answers for entries inside y): norm1 of a windowed block followed by window_partition
+ * (segment_anything/modeling/image_encoder.py:176-180,243-263) in one pass - the padding rows of the windows are
+ * rows of y that no entry names and stay what they were (zero).  16-byte aligned rows, D a multiple of 4. */
+int marship_layernorm_rows(const float* x, int64_t x_stride, const float* w, const float* b, void* y, int64_t y_stride,
+                           int rows, int D, float eps, const int32_t* out_rows, int out_dtype, void* stream);
 /* The same LayerNorm (clip/model.py:265-271, alpha_clip/model.py:254-258) folded into the products on either
  * side of it, see MarsGemm.ln_*: marship_ln_finish turns the row sums a stream product left in ln_part
  * ([rows, nparts, 2], nparts = N/64) into stat [rows, 2] = mean, 1/sqrt(var + eps) (var = E[x^2] - mean^2 in
@@ -295,6 +301,11 @@ int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd
  * T <= 65536, Wk <= 65535, scale > 0. */
 int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
                      int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream);
+/* The same, with the result of token row r = b*T + t written to row out_rows[r] of O (i32 on the device; negative:
+ * dropped; the caller answers for entries inside O): the attention of a windowed block followed by
+ * window_unpartition (image_encoder.py:183-185,266-289), which drops the windows' padding tokens. */
+int marship_sam_attn_rows(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
+                          int nb, int T, int H, int hdp, int Hk, int Wk, float scale, const int32_t* out_rows, void* stream);
 /* P[row, k] = softmax_k(S[row, k] + rel_h[row, k / Wk] + rel_w[row, k % Wk]) (image_encoder.py:357-359,236;
  * without the bias terms: transformer.py:231-233), zeros in columns T..ldp-1.  Rows up to 16384 long. */
 int marship_softmax_bias_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t nrows, int T,

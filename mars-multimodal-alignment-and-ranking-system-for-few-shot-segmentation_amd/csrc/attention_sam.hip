@@ -52,7 +52,7 @@ template <int HD, int QB, bool ROWTILE, int NW = 4, bool ALLKV = false>
 __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn_kernel(const __bf16* __restrict__ qkv, int64_t ld, __bf16* __restrict__ O,
                                                           int64_t ldo, const float* __restrict__ rel_h,
                                                           const float* __restrict__ rel_w, int T, int H, int Hk, int Wk,
-                                                          float c2, unsigned wk_magic) {
+                                                          float c2, unsigned wk_magic, const int32_t* __restrict__ out_rows) {
     constexpr int ROWB = HD * 2, KS = (HD + 31) / 32, DM = HD / 16, QPB = NW * QB * 16;
     constexpr bool LINEAR = (1024 % ROWB) != 0;    // rows that do not tile a 1-KiB fill piece: no swizzle
     static_assert(!ALLKV || QB == 1, "the resident form walks one 16-query block a wave at a time");
@@ -318,7 +318,9 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
             const int myq = q0 + qb * 16 + r16;
             if (myq < T) {
                 const float inv = 1.0f / o[qb][DM][0];
-                __bf16* op = O + ((int64_t)b * T + myq) * ldo + h * HD;
+                const int64_t orow = out_rows ? out_rows[(int64_t)b * T + myq] : (int64_t)b * T + myq;      // (negative: not written)
+                if (orow < 0) continue;
+                __bf16* op = O + orow * ldo + h * HD;
 #pragma unroll
                 for (int m = 0; m < DM; ++m) {
                     bf16x4 v;
@@ -372,13 +374,13 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
 
 template <int HD, int QB>
 int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w, int nb, int T,
-           int H, int Hk, int Wk, float c2, hipStream_t s) {
+           int H, int Hk, int Wk, float c2, const int32_t* out_rows, hipStream_t s) {
     const unsigned wk_magic = Wk > 1 ? (unsigned)((0x100000000ull + (unsigned)Wk - 1) / (unsigned)Wk) : 0u;      // (a grid one token wide does not use it)
     if constexpr (QB == 1) {
         // every key of a small token grid (the windows) resident in LDS: one workgroup of eight waves per (image, head)
         if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) {
             hipLaunchKernelGGL((sam_attn_kernel<HD, 1, false, 8, true>), dim3(1, nb * H), dim3(512), 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h,
-                               rel_w, T, H, Hk, Wk, c2, wk_magic);
+                               rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows);
             MARS_LAUNCH_CHECK();
             return 0;
         }
@@ -387,17 +389,17 @@ int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h
     dim3 grid((T + QPB - 1) / QPB, nb * H), block(256);
     // one key row per tile: no division, and whole 16-byte loads of rel_w (rows of 64 floats are 16-byte aligned)
     if (Wk == KT && T == Hk * Wk && ((uintptr_t)rel_w % 16) == 0)
-        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, true>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic);
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, true>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows);
     else
-        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, false>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic);
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, false>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows);
     MARS_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
-                                int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream) {
+extern "C" int marship_sam_attn_rows(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
+                                     int nb, int T, int H, int hdp, int Hk, int Wk, float scale, const int32_t* out_rows, void* stream) {
     MARS_CHECK(qkv && O && rel_h && rel_w, "sam_attn: null pointer");
     MARS_CHECK(nb > 0 && T > 0 && H > 0 && Hk > 0 && Wk > 0 && Hk * Wk >= T, "sam_attn: bad shape nb=%d T=%d H=%d Hk=%d Wk=%d", nb, T, H, Hk, Wk);
     MARS_CHECK(hdp == 64 || hdp == 80 || hdp == 128, "sam_attn: head dim as stored %d (64, 80 or 128)", hdp);
@@ -409,15 +411,20 @@ extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ld
     const float c2 = scale * 1.4426950408889634f;
     if (hdp == 64) {
         // (the windows: every key resident, one 16-query block a wave at a time)
-        if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) return launch<64, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
-        return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+        if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) return launch<64, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
+        return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
     }
     if (hdp == 80) {
         // long rows (the global blocks): two 16-query blocks a wave share every K / V tile the workgroup brings in
         // (the one-key-row-per-tile form only: the general bias lookup does not fit beside two blocks' accumulators)
         if (T >= 1024 && Wk == KT && T == Hk * Wk && ((uintptr_t)rel_w % 16) == 0)
-            return launch<80, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
-        return launch<80, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+            return launch<80, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
+        return launch<80, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
     }
-    return launch<128, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, (hipStream_t)stream);
+    return launch<128, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
+}
+
+extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
+                                int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream) {
+    return marship_sam_attn_rows(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, hdp, Hk, Wk, scale, nullptr, stream);
 }

@@ -52,10 +52,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <typename TOUT, int NCH>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int64_t xs,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            TOUT* __restrict__ y, int64_t ys, int rows, int D, float eps) {
+                                                            TOUT* __restrict__ y, int64_t ys, int rows, int D, float eps,
+                                                            const int32_t* __restrict__ out_rows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
+    const int64_t orow = out_rows ? out_rows[row] : row;          // (a negative entry: the row is not written)
+    if (orow < 0) return;
     const f32x4* xr = (const f32x4*)(x + (int64_t)row * xs);
     const int nc = D >> 2;                 // chunks per row
     f32x4 v[NCH];                          // NCH = ceil(D / 256) chunks per lane
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-    TOUT* yr = y + (int64_t)row * ys;
+    TOUT* yr = y + orow * ys;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = i * 64 + lane;
@@ -352,8 +355,8 @@ inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
 
 }  // namespace
 
-extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
-                                 int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream) {
+static int layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* y, int64_t y_stride, int rows, int D,
+                            float eps, const int32_t* out_rows, int out_dtype, void* stream) {
     MARS_CHECK(x && w && b && y, "layernorm: null pointer");
     MARS_CHECK(rows > 0 && D > 0 && D <= 2048, "layernorm: D=%d out of range (1..2048)", D);
     dim3 grid((rows + 3) / 4), block(256);
@@ -363,15 +366,29 @@ extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* 
     if (vec) {
         const int nch = (D / 4 + 63) / 64;
 #define MARS_LN(N)                                                                                                         \
-        if (out_dtype == 1) hipLaunchKernelGGL((layernorm_vec_kernel<__bf16, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps); \
-        else hipLaunchKernelGGL((layernorm_vec_kernel<float, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
+        if (out_dtype == 1) hipLaunchKernelGGL((layernorm_vec_kernel<__bf16, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps, out_rows); \
+        else hipLaunchKernelGGL((layernorm_vec_kernel<float, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps, out_rows);
         if (nch <= 1) { MARS_LN(1) } else if (nch == 2) { MARS_LN(2) } else if (nch == 3) { MARS_LN(3) } else if (nch == 4) { MARS_LN(4) }
         else if (nch <= 6) { MARS_LN(6) } else { MARS_LN(8) }
 #undef MARS_LN
-    } else if (out_dtype == 1) hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
+    } else {
+        MARS_CHECK(!out_rows, "layernorm_rows: rows and pointers must be 16-byte aligned, D a multiple of 4");
+        if (out_dtype == 1) hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps);
+        else hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
+    }
     MARS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
+                                 int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream) {
+    return layernorm_launch(x, x_stride, w, b, y, y_stride, rows, D, eps, nullptr, out_dtype, stream);
+}
+
+extern "C" int marship_layernorm_rows(const float* x, int64_t x_stride, const float* w, const float* b, void* y, int64_t y_stride, int rows,
+                                      int D, float eps, const int32_t* out_rows, int out_dtype, void* stream) {
+    MARS_CHECK(out_rows, "layernorm_rows: null row map");
+    return layernorm_launch(x, x_stride, w, b, y, y_stride, rows, D, eps, out_rows, out_dtype, stream);
 }
 
 extern "C" int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, float* watch,

@@ -239,14 +239,23 @@ def row_stats(x: torch.Tensor, eps: float, hi: torch.Tensor, lo: torch.Tensor, s
                                           stream()), "marship_row_stats")
 
 
-def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float):
-    _dev(x, w, b, out)
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float, out_rows: Optional[torch.Tensor] = None):
+    """out[r] = LayerNorm(x[r]); with ``out_rows`` (i32 on the device, one entry a row of x, the caller's own map: every entry
+    negative or a row of ``out``): out[out_rows[r]] = LayerNorm(x[r]), rows of ``out`` that no entry names are left alone."""
+    _dev(x, w, b, out, out_rows)
     _req(x.dtype == torch.float32 and x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1, "layernorm: bad x/out")
     rows, D = x.shape
-    _req(out.shape[0] == rows and out.shape[1] == D and w.numel() == D and b.numel() == D, "layernorm: shape mismatch")
-    _req((rows - 1) * x.stride(0) + D <= _avail(x) and (rows - 1) * out.stride(0) + D <= _avail(out), "layernorm: overrun")
-    hip.check(hip.lib().marship_layernorm(ptr(x), x.stride(0), ptr(w), ptr(b), ptr(out), out.stride(0), rows, D, eps,
-                                          dt(out), stream()), "marship_layernorm")
+    _req(out.shape[1] == D and w.numel() == D and b.numel() == D, "layernorm: shape mismatch")
+    _req((rows - 1) * x.stride(0) + D <= _avail(x), "layernorm: overrun")
+    if out_rows is None:
+        _req(out.shape[0] == rows and (rows - 1) * out.stride(0) + D <= _avail(out), "layernorm: overrun")
+        hip.check(hip.lib().marship_layernorm(ptr(x), x.stride(0), ptr(w), ptr(b), ptr(out), out.stride(0), rows, D, eps,
+                                              dt(out), stream()), "marship_layernorm")
+        return
+    _req(out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() >= rows, "layernorm: out_rows must be i32, one entry a row")
+    _req((out.shape[0] - 1) * out.stride(0) + D <= _avail(out), "layernorm: overrun")
+    hip.check(hip.lib().marship_layernorm_rows(ptr(x), x.stride(0), ptr(w), ptr(b), ptr(out), out.stride(0), rows, D, eps, ptr(out_rows),
+                                               dt(out), stream()), "marship_layernorm_rows")
 
 
 def im2col(img: torch.Tensor, p: int, out: torch.Tensor, *, mean=None, std=None, prescale: float = 1.0, col_off: int = 0):
@@ -643,14 +652,22 @@ def relpos_bias(qkv: torch.Tensor, B: int, T: int, H: int, hd: int, hdp: int, gw
 
 
 def sam_attn(qkv: torch.Tensor, out: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, nb: int, T: int, H: int, hdp: int,
-             Hk: int, Wk: int, scale: float):
-    """out[nb*T, H*hdp] = attention of packed bf16 qkv rows with the decomposed relative-position bias, fused."""
-    _dev(qkv, out, rel_h, rel_w)
+             Hk: int, Wk: int, scale: float, out_rows: Optional[torch.Tensor] = None):
+    """out[nb*T, H*hdp] = attention of packed bf16 qkv rows with the decomposed relative-position bias, fused.  With ``out_rows``
+    (i32 on the device, one entry a token row, the caller's own map: every entry negative or a row of ``out``) the result of
+    token row r goes to out[out_rows[r]], or nowhere for a negative entry."""
+    _dev(qkv, out, rel_h, rel_w, out_rows)
     _req(qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and qkv.dim() == 2 and out.dim() == 2, "sam_attn: bf16 rows")
-    _req(qkv.stride(1) == 1 and out.stride(1) == 1 and qkv.shape[0] >= nb * T and out.shape[0] >= nb * T, "sam_attn: rows")
+    _req(qkv.stride(1) == 1 and out.stride(1) == 1 and qkv.shape[0] >= nb * T and (out_rows is not None or out.shape[0] >= nb * T), "sam_attn: rows")
+    _req(out_rows is None or (out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() >= nb * T),
+         "sam_attn: out_rows must be i32, one entry a token row")
     _req(qkv.shape[1] >= 3 * H * hdp and out.shape[1] >= H * hdp, "sam_attn: columns")
     _req(rel_h.dtype == torch.float32 and rel_w.dtype == torch.float32 and rel_h.numel() >= nb * H * T * Hk and rel_w.numel() >= nb * H * T * Wk,
          "sam_attn: bias terms")
+    if out_rows is not None:
+        hip.check(hip.lib().marship_sam_attn_rows(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(rel_h), ptr(rel_w), nb, T, H, hdp, Hk, Wk,
+                                                  scale, ptr(out_rows), stream()), "marship_sam_attn_rows")
+        return
     hip.check(hip.lib().marship_sam_attn(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(rel_h), ptr(rel_w), nb, T, H, hdp, Hk, Wk,
                                          scale, stream()), "marship_sam_attn")
 

@@ -152,6 +152,7 @@ class ImageEncoderViT:
         self.neck3 = (_dev_f32(sd[prefix + ".neck.3.weight"], dev), _dev_f32(sd[prefix + ".neck.3.bias"], dev))
         self._attn = _Attn(dev, dtype)
         self.fused_attention = fused_ok and hdp in (64, 80, 128)
+        self.fused_partition = os.environ.get("MARS_SAM_FUSED_PARTITION", "1") != "0"
         self._build_index_maps()
         self._mean = torch.tensor(PIXEL_MEAN, dtype=torch.float32, device=dev)
         self._std = torch.tensor(PIXEL_STD, dtype=torch.float32, device=dev)
@@ -202,9 +203,16 @@ class ImageEncoderViT:
         ops.linear(w["a0"], self.patch.w, w["X"], bias=self.patch.b, residual=self.pos)       # patch embed + pos embed
         X = w["X"]
         for b in self.blocks:
-            ops.layernorm(X, b.ln1[0], b.ln1[1], w["xn"], 1e-6)
+            # (fused_partition: norm1 writes the rows of the windows and the attention the rows of the image; the windows'
+            # padding rows of xw are never written and stay the zeros they were made as)
+            fp = self.fused_partition and b.ws > 0 and self.fused_attention
+            if fp:
+                ops.layernorm(X, b.ln1[0], b.ln1[1], w["xw"], 1e-6, out_rows=self.unpart_idx)
+            else:
+                ops.layernorm(X, b.ln1[0], b.ln1[1], w["xn"], 1e-6)
             if b.ws > 0:
-                ops.gather_rows(w["xn"], self.part_idx, w["xw"])                                 # zero rows for the padding
+                if not fp:
+                    ops.gather_rows(w["xn"], self.part_idx, w["xw"])                             # zero rows for the padding
                 src, nb, Tt, gw = w["xw"], self.n_win, b.ws * b.ws, b.ws
             else:
                 src, nb, Tt, gw = w["xn"], 1, T, G
@@ -215,14 +223,17 @@ class ImageEncoderViT:
             rel_w = self._rel_buf("w", nb * H * Tt * gw)
             ops.relpos_bias(qkv, nb, Tt, H, hd, hdp, gw, b.Rh, b.Rw, rel_h, rel_w)
             ao = w["ao"][:rows]
-            if self.fused_attention:
+            if fp:
+                ao = w["aou"]
+                ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5, out_rows=self.part_idx)
+            elif self.fused_attention:
                 ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5)
             else:
                 if hdp % 64:
                     raise RuntimeError("this tower stores its heads unpadded for the fused attention kernel; build it with MARS_FLASH=0 "
                                        "(or MARS_SAM_HEAD80=0) to run the three-launch form")
                 self._attn.run(qkv, 0, qkv, H * hdp, qkv, 2 * H * hdp, ao, nb, H, Tt, Tt, hdp, hd ** -0.5, rel=(rel_h, rel_w, Tt // gw, gw))
-            if b.ws > 0:
+            if b.ws > 0 and not fp:
                 ops.gather_rows(ao, self.unpart_idx, w["aou"])
                 ao = w["aou"]
             ops.linear(ao[:T], b.proj.w, X, bias=b.proj.b, residual=X)

@@ -399,6 +399,65 @@ def test_fused_attention_with_relpos_bias(pkg, nb, gh, gw, H, hd, hdp):
         assert float(out.view(nb * T, H, hdp)[..., hd:].abs().max()) == 0.0
 
 
+def test_row_maps_of_layernorm_and_attention_equal_the_gathers(pkg):
+    """norm1 writing the rows of the windows and the attention writing the rows of the image (row maps inside the two
+    kernels) == the same kernels followed by gather_rows, bit for bit; rows that no entry names keep their contents."""
+    ops = pkg.ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(12)
+    G, ws, D = 20, 14, 160
+    nw = -(-G // ws)
+    part = torch.full((nw * nw * ws * ws,), -1, dtype=torch.int32)
+    unpart = torch.zeros(G * G, dtype=torch.int32)
+    for wy in range(nw):
+        for wx in range(nw):
+            for iy in range(ws):
+                for ix in range(ws):
+                    y, x = wy * ws + iy, wx * ws + ix
+                    if y < G and x < G:
+                        r = ((wy * nw + wx) * ws + iy) * ws + ix
+                        part[r] = y * G + x
+                        unpart[y * G + x] = r
+    part, unpart = part.to(dev), unpart.to(dev)
+    X = torch.randn(G * G, D, generator=g).to(dev)
+    w, b = torch.randn(D, generator=g).to(dev), torch.randn(D, generator=g).to(dev)
+    xn = torch.empty(G * G, D, dtype=torch.bfloat16, device=dev)
+    ops.layernorm(X, w, b, xn, 1e-6)
+    want = torch.empty(part.numel(), D, dtype=torch.bfloat16, device=dev)
+    ops.gather_rows(xn, part, want)
+    got = torch.zeros_like(want)
+    ops.layernorm(X, w, b, got, 1e-6, out_rows=unpart)
+    assert torch.equal(got, want)
+    # attention of the windows, written back in image order
+    H, hd = 2, 80
+    T, nb = ws * ws, nw * nw
+    qkv = (torch.randn(nb * T, 3 * H * hd, generator=g)).to(torch.bfloat16).to(dev)
+    rel_h = (torch.randn(nb * H, T, ws, generator=g)).to(dev)
+    rel_w = (torch.randn(nb * H, T, ws, generator=g)).to(dev)
+    ao = torch.empty(nb * T, H * hd, dtype=torch.bfloat16, device=dev)
+    ops.sam_attn(qkv, ao, rel_h, rel_w, nb, T, H, hd, ws, ws, hd ** -0.5)
+    want = torch.empty(G * G, H * hd, dtype=torch.bfloat16, device=dev)
+    ops.gather_rows(ao, unpart, want)
+    got = torch.full_like(want, 7.0)
+    ops.sam_attn(qkv, got, rel_h, rel_w, nb, T, H, hd, ws, ws, hd ** -0.5, out_rows=part)
+    assert torch.equal(got, want)
+
+
+def test_encoder_with_row_maps_equals_the_gathers(pkg, monkeypatch):
+    sa = pkg.segment_anything
+    sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["tiny80"], seed=5)
+    img = GOLD["sam_tiny80_image"]
+    feats = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MARS_SAM_FUSED_PARTITION", flag)
+        sam = sa.sam_model_registry["tiny80"](state_dict=sd, device="cuda", dtype=torch.bfloat16)
+        pred = sa.SamPredictor(sam)
+        pred.set_image(img)
+        pred.set_image(img)                                  # (a second image through the same work buffers)
+        feats.append(pred.features.float().clone())
+    assert torch.equal(feats[0], feats[1])
+
+
 @pytest.mark.parametrize("arch", ["tiny", "tiny80"])
 def test_encoder_fused_attention_agrees_with_three_launch_form(pkg, arch, monkeypatch):
     """bf16 encoder with the fused attention against the same encoder with scores, softmax and P.V as three
