@@ -96,12 +96,6 @@ int marship_set_gemm_slots(int slots);
  * eps 1e-5, computed in f32).  x f32 [rows, D] with row stride x_stride; y out_dtype. */
 int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
                       int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream);
-/* The same, with row r written to row out_rows[r] of y (i32 on the device; a negative entry: not written; the caller
- * answers for entries inside y): norm1 of a windowed block followed by window_partition
- * (segment_anything/modeling/image_encoder.py:176-180,243-263) in one pass - the padding rows of the windows are
- * rows of y that no entry names and stay what they were (zero).  16-byte aligned rows, D a multiple of 4. */
-int marship_layernorm_rows(const float* x, int64_t x_stride, const float* w, const float* b, void* y, int64_t y_stride,
-                           int rows, int D, float eps, const int32_t* out_rows, int out_dtype, void* stream);
 /* The same LayerNorm (clip/model.py:265-271, alpha_clip/model.py:254-258) folded into the products on either
  * side of it, see MarsGemm.ln_*: marship_ln_finish turns the row sums a stream product left in ln_part
  * ([rows, nparts, 2], nparts = N/64) into stat [rows, 2] = mean, 1/sqrt(var + eps) (var = E[x^2] - mean^2 in
@@ -293,6 +287,11 @@ int marship_attn_small(const void* q, int64_t ldq, const void* k, int64_t ldk, c
 int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd, int hdp, int gw,
                         int Hk, int Wk, const float* Rh, const float* Rw, float* rel_h, float* rel_w,
                         int dtype, void* stream);
+/* The same with the queries of token row r = b*T + t read from row in_rows[r] of qkv, or from pad_row for a negative
+ * entry (as marship_sam_attn_rows): bf16 queries, grids and tables up to 16 a side, head dims a multiple of 8 up to 128. */
+int marship_relpos_bias_rows(const void* qkv, int64_t ld, int B, int T, int H, int hd, int hdp, int gw,
+                             int Hk, int Wk, const float* Rh, const float* Rw, float* rel_h, float* rel_w,
+                             const int32_t* in_rows, const void* pad_row, int dtype, void* stream);
 /* The attention of an encoder block in one kernel, without the score matrix (image_encoder.py:224-240 with the
  * bias of :357-359): O[b*T+t, head*hdp+d] = sum_k softmax_k(scale q.k + rel_h[.., k / Wk] + rel_w[.., k % Wk]) v[k, d]
  * for bf16 qkv rows (row stride ld; q, k, v of head h at columns h*hdp, (H+h)*hdp, (2H+h)*hdp), hdp 64 or 128
@@ -301,11 +300,15 @@ int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd
  * T <= 65536, Wk <= 65535, scale > 0. */
 int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
                      int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream);
-/* The same, with the result of token row r = b*T + t written to row out_rows[r] of O (i32 on the device; negative:
- * dropped; the caller answers for entries inside O): the attention of a windowed block followed by
- * window_unpartition (image_encoder.py:183-185,266-289), which drops the windows' padding tokens. */
+/* The same for windows that are not materialised (window_partition and window_unpartition,
+ * image_encoder.py:176-185,243-289, inside the kernel): qkv holds the image's rows; token row r = b*T + t of the windows
+ * is row in_rows[r] of qkv (i32 on the device), or - for a negative entry, a window's padding token - pad_row, one row in
+ * the layout of a qkv row that holds what the projection makes of a zero input (its bias); the result of token row r is
+ * written to row out_rows[r] of O, or dropped for a negative entry.  Either map may be null (rows in place).  The caller
+ * answers for entries inside qkv and O. */
 int marship_sam_attn_rows(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
-                          int nb, int T, int H, int hdp, int Hk, int Wk, float scale, const int32_t* out_rows, void* stream);
+                          int nb, int T, int H, int hdp, int Hk, int Wk, float scale, const int32_t* in_rows,
+                          const void* pad_row, const int32_t* out_rows, void* stream);
 /* P[row, k] = softmax_k(S[row, k] + rel_h[row, k / Wk] + rel_w[row, k % Wk]) (image_encoder.py:357-359,236;
  * without the bias terms: transformer.py:231-233), zeros in columns T..ldp-1.  Rows up to 16384 long. */
 int marship_softmax_bias_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t nrows, int T,

@@ -48,11 +48,12 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 a, f32x4 b) {
 // LDS by one burst of fills and one barrier, then every wave walks its 16-query blocks over the resident tiles.  With
 // four 64-query workgroups per (window, head), each re-filling the same 196 keys tile by tile behind a barrier, the
 // windowed blocks spent their time waiting: four dependent fill latencies for a few hundred matrix instructions.
-template <int HD, int QB, bool ROWTILE, int NW = 4, bool ALLKV = false>
+template <int HD, int QB, bool ROWTILE, int NW = 4, bool ALLKV = false, bool ROWMAP = false>
 __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn_kernel(const __bf16* __restrict__ qkv, int64_t ld, __bf16* __restrict__ O,
                                                           int64_t ldo, const float* __restrict__ rel_h,
                                                           const float* __restrict__ rel_w, int T, int H, int Hk, int Wk,
-                                                          float c2, unsigned wk_magic, const int32_t* __restrict__ out_rows) {
+                                                          float c2, unsigned wk_magic, const int32_t* __restrict__ out_rows,
+                                                          const int32_t* __restrict__ in_rows, const __bf16* __restrict__ pad_row) {
     constexpr int ROWB = HD * 2, KS = (HD + 31) / 32, DM = HD / 16, QPB = NW * QB * 16;
     constexpr bool LINEAR = (1024 % ROWB) != 0;    // rows that do not tile a 1-KiB fill piece: no swizzle
     static_assert(!ALLKV || QB == 1, "the resident form walks one 16-query block a wave at a time");
@@ -79,6 +80,13 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
     const int64_t row_b = ld * 2;                  // bytes per token row of qkv
     const unsigned char* base = (const unsigned char*)qkv + (int64_t)b * T * row_b + (int64_t)h * ROWB;
     const int64_t opnd_b = (int64_t)H * ROWB;      // bytes from q to k and from k to v inside a row
+    // token row t of this image (window): its row of qkv, or - with a row map - the row the map names, or the row of
+    // padding values (what the projection makes of a zero input: its bias) for a negative entry
+    auto token_row = [&](int t) -> const unsigned char* {
+        if (!ROWMAP || !in_rows) return base + (int64_t)t * row_b;
+        const int r = in_rows[(int64_t)b * T + t];
+        return r >= 0 ? (const unsigned char*)qkv + (int64_t)r * row_b + (int64_t)h * ROWB : (const unsigned char*)pad_row + (int64_t)h * ROWB;
+    };
     const bool wave_active = q0 < T;               // trailing waves of the last workgroup only help with the fills
 
     bf16x8 qf[QB][KS];
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const int qrow = min(q0 + qb * 16 + r16, T - 1);
-            const unsigned char* qp = base + (int64_t)qrow * row_b;
+            const unsigned char* qp = token_row(qrow);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 qf[qb][ks] = bf16x8{};
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
             const int c = pp * 64 + lane, row = c / LPR, slot = c - row * LPR;
             const int chunk = LINEAR ? slot : slot ^ ((row >> 1) & 7);
             const int key = min(t * KT + row, T - 1);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (1 + opnd) * opnd_b + (int64_t)key * row_b + chunk * 16),
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(token_row(key) + (1 + opnd) * opnd_b + chunk * 16),
                                              (lds_ptr_t)(tile(buf, opnd) + pp * 1024), 16, 0, 0);
         }
     };
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
             const int myq = q0 + qb * 16 + r16;
             if (myq < T) {
                 const float inv = 1.0f / o[qb][DM][0];
-                const int64_t orow = out_rows ? out_rows[(int64_t)b * T + myq] : (int64_t)b * T + myq;      // (negative: not written)
+                const int64_t orow = (ROWMAP && out_rows) ? out_rows[(int64_t)b * T + myq] : (int64_t)b * T + myq;      // (negative: not written)
                 if (orow < 0) continue;
                 __bf16* op = O + orow * ldo + h * HD;
 #pragma unroll
@@ -333,7 +341,32 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
     };
 
     if constexpr (ALLKV) {
-        for (int t = 0; t < nt; ++t) issue_tile(t, t);
+        if constexpr (ROWMAP) {
+            // the source rows of every fill piece of this wave first (independent loads), then the fills
+            constexpr int PW = (2 * PPO + NW - 1) / NW;
+            const unsigned char* src[4][PW];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < PW; ++i) {
+                    const int p = wave + i * NW, pp = p % PPO;
+                    const int c = pp * 64 + lane, row = c / LPR;
+                    src[t][i] = base;
+                    if (t < nt && p < 2 * PPO) src[t][i] = token_row(min(t * KT + row, T - 1));
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < PW; ++i) {
+                    const int p = wave + i * NW, opnd = p / PPO, pp = p % PPO;
+                    if (t >= nt || p >= 2 * PPO || (t == 3 && pp >= PPO / 2)) continue;
+                    const int c = pp * 64 + lane, row = c / LPR, slot = c - row * LPR;
+                    const int chunk = LINEAR ? slot : slot ^ ((row >> 1) & 7);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[t][i] + (1 + opnd) * opnd_b + chunk * 16), (lds_ptr_t)(tile(t, opnd) + pp * 1024), 16, 0, 0);
+                }
+        } else {
+            for (int t = 0; t < nt; ++t) issue_tile(t, t);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // (q0 of the first pass is this wave's block of workgroup 0: the grid has one workgroup per (image, head))
@@ -374,24 +407,29 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
 
 template <int HD, int QB>
 int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w, int nb, int T,
-           int H, int Hk, int Wk, float c2, const int32_t* out_rows, hipStream_t s) {
+           int H, int Hk, int Wk, float c2, const int32_t* out_rows, const int32_t* in_rows, const __bf16* pad_row, hipStream_t s) {
     const unsigned wk_magic = Wk > 1 ? (unsigned)((0x100000000ull + (unsigned)Wk - 1) / (unsigned)Wk) : 0u;      // (a grid one token wide does not use it)
     if constexpr (QB == 1) {
         // every key of a small token grid (the windows) resident in LDS: one workgroup of eight waves per (image, head)
         if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) {
-            hipLaunchKernelGGL((sam_attn_kernel<HD, 1, false, 8, true>), dim3(1, nb * H), dim3(512), 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h,
-                               rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows);
+            if (in_rows || out_rows)
+                hipLaunchKernelGGL((sam_attn_kernel<HD, 1, false, 8, true, true>), dim3(1, nb * H), dim3(512), 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo,
+                                   rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows, in_rows, pad_row);
+            else
+                hipLaunchKernelGGL((sam_attn_kernel<HD, 1, false, 8, true>), dim3(1, nb * H), dim3(512), 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h,
+                                   rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows, in_rows, pad_row);
             MARS_LAUNCH_CHECK();
             return 0;
         }
     }
+    MARS_CHECK(!in_rows && !out_rows, "sam_attn_rows: row maps go with the windows' kernel: one 16-query block a wave form, 64 < T <= 224 tokens (T=%d)", T);
     constexpr int QPB = 4 * QB * 16;
     dim3 grid((T + QPB - 1) / QPB, nb * H), block(256);
     // one key row per tile: no division, and whole 16-byte loads of rel_w (rows of 64 floats are 16-byte aligned)
     if (Wk == KT && T == Hk * Wk && ((uintptr_t)rel_w % 16) == 0)
-        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, true>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows);
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, true>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows, in_rows, pad_row);
     else
-        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, false>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows);
+        hipLaunchKernelGGL((sam_attn_kernel<HD, QB, false>), grid, block, 0, s, (const __bf16*)qkv, ld, (__bf16*)O, ldo, rel_h, rel_w, T, H, Hk, Wk, c2, wk_magic, out_rows, in_rows, pad_row);
     MARS_LAUNCH_CHECK();
     return 0;
 }
@@ -399,8 +437,10 @@ int launch(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h
 }  // namespace
 
 extern "C" int marship_sam_attn_rows(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
-                                     int nb, int T, int H, int hdp, int Hk, int Wk, float scale, const int32_t* out_rows, void* stream) {
+                                     int nb, int T, int H, int hdp, int Hk, int Wk, float scale, const int32_t* in_rows, const void* pad_row,
+                                     const int32_t* out_rows, void* stream) {
     MARS_CHECK(qkv && O && rel_h && rel_w, "sam_attn: null pointer");
+    MARS_CHECK(!in_rows || (pad_row && ((uintptr_t)pad_row % 16) == 0), "sam_attn: a row map needs the 16-byte aligned row of padding values");
     MARS_CHECK(nb > 0 && T > 0 && H > 0 && Hk > 0 && Wk > 0 && Hk * Wk >= T, "sam_attn: bad shape nb=%d T=%d H=%d Hk=%d Wk=%d", nb, T, H, Hk, Wk);
     MARS_CHECK(hdp == 64 || hdp == 80 || hdp == 128, "sam_attn: head dim as stored %d (64, 80 or 128)", hdp);
     MARS_CHECK(ld >= 3 * (int64_t)H * hdp && ld % 8 == 0 && ldo >= (int64_t)H * hdp && ldo % 4 == 0, "sam_attn: row strides");
@@ -411,20 +451,20 @@ extern "C" int marship_sam_attn_rows(const void* qkv, int64_t ld, void* O, int64
     const float c2 = scale * 1.4426950408889634f;
     if (hdp == 64) {
         // (the windows: every key resident, one 16-query block a wave at a time)
-        if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) return launch<64, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
-        return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
+        if (T <= 3 * KT + 32 && T > KT && !(Wk == KT && T == Hk * Wk)) return launch<64, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, in_rows, (const __bf16*)pad_row, (hipStream_t)stream);
+        return launch<64, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, in_rows, (const __bf16*)pad_row, (hipStream_t)stream);
     }
     if (hdp == 80) {
         // long rows (the global blocks): two 16-query blocks a wave share every K / V tile the workgroup brings in
         // (the one-key-row-per-tile form only: the general bias lookup does not fit beside two blocks' accumulators)
         if (T >= 1024 && Wk == KT && T == Hk * Wk && ((uintptr_t)rel_w % 16) == 0)
-            return launch<80, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
-        return launch<80, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
+            return launch<80, 2>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, in_rows, (const __bf16*)pad_row, (hipStream_t)stream);
+        return launch<80, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, in_rows, (const __bf16*)pad_row, (hipStream_t)stream);
     }
-    return launch<128, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, (hipStream_t)stream);
+    return launch<128, 1>(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, Hk, Wk, c2, out_rows, in_rows, (const __bf16*)pad_row, (hipStream_t)stream);
 }
 
 extern "C" int marship_sam_attn(const void* qkv, int64_t ld, void* O, int64_t ldo, const float* rel_h, const float* rel_w,
                                 int nb, int T, int H, int hdp, int Hk, int Wk, float scale, void* stream) {
-    return marship_sam_attn_rows(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, hdp, Hk, Wk, scale, nullptr, stream);
+    return marship_sam_attn_rows(qkv, ld, O, ldo, rel_h, rel_w, nb, T, H, hdp, Hk, Wk, scale, nullptr, nullptr, nullptr, stream);
 }

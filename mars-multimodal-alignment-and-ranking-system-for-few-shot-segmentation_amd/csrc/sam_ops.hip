@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void relpos_bias_kernel(const T* __restrict__ 
 // layer launched 11200 workgroups of which a fifth of the threads had work.
 __global__ __launch_bounds__(256) void relpos_bias_mma_kernel(const __bf16* __restrict__ qkv, int64_t ld, int Tn, int H, int hd, int hdp, int gw,
                                                               int Hk, int Wk, const float* __restrict__ Rh, const float* __restrict__ Rw,
-                                                              float* __restrict__ rel_h, float* __restrict__ rel_w, int64_t nslices) {
+                                                              float* __restrict__ rel_h, float* __restrict__ rel_w, int64_t nslices,
+                                                              const int32_t* __restrict__ in_rows, const __bf16* __restrict__ pad_row) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
     const int gh = Tn / gw, nsl = gh + gw;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -137,7 +138,9 @@ __global__ __launch_bounds__(256) void relpos_bias_mma_kernel(const __bf16* __re
     const int64_t b = bh / H;
     const int n = min(r16, nq - 1);
     const int t = along_w ? n * gw + fixed : fixed * gw + n;
-    const __bf16* qp = qkv + (b * Tn + t) * ld + (int64_t)head * hdp;
+    // (with a row map: the row of qkv that the map names for token row b Tn + t, the row of padding values for a negative entry)
+    const int64_t qr = in_rows ? in_rows[b * Tn + t] : b * Tn + t;
+    const __bf16* qp = (qr >= 0 ? qkv + qr * ld : pad_row) + (int64_t)head * hdp;
     const float* table = (along_w ? Rw + (int64_t)fixed * Wk * hd : Rh + (int64_t)fixed * Hk * hd) + (int64_t)min(r16, nk - 1) * hd;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // every load of the slice is requested before the first product (head dims up to 128: four K steps; the same trips
@@ -875,23 +878,27 @@ extern "C" int marship_gather_rows(const void* src, int64_t ld_src, int src_col,
     return 0;
 }
 
-extern "C" int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd, int hdp, int gw, int Hk, int Wk,
-                                   const float* Rh, const float* Rw, float* rel_h, float* rel_w, int dtype, void* stream) {
+extern "C" int marship_relpos_bias_rows(const void* qkv, int64_t ld, int B, int T, int H, int hd, int hdp, int gw, int Hk, int Wk,
+                                        const float* Rh, const float* Rw, float* rel_h, float* rel_w, const int32_t* in_rows, const void* pad_row,
+                                        int dtype, void* stream) {
     MARS_CHECK(qkv && Rh && Rw && rel_h && rel_w, "relpos_bias: null pointer");
     MARS_CHECK(B > 0 && T > 0 && H > 0 && hd > 0 && hdp >= hd && gw > 0 && T % gw == 0 && Hk > 0 && Wk > 0 && ld >= (int64_t)H * hdp,
                "relpos_bias: bad shape");
     const int gh = T / gw;
     const int nmax = gh > gw ? gh : gw, kmax = Hk > Wk ? Hk : Wk;
     // small grids of bf16 queries: a wave per table slice on the matrix pipe (MARS_RELPOS_MMA=0, read once: the vector form)
-    static const bool mma = [] { const char* e = getenv("MARS_RELPOS_MMA"); return !(e && e[0] == '0'); }();
+    static const bool mma_on = [] { const char* e = getenv("MARS_RELPOS_MMA"); return !(e && e[0] == '0'); }();
+    const bool mma = mma_on || in_rows;
+    MARS_CHECK(!in_rows || (pad_row && ((uintptr_t)pad_row % 16) == 0), "relpos_bias_rows: a row map needs the 16-byte aligned row of padding values");
     if (mma && dtype == 1 && nmax <= 16 && kmax <= 16 && hd % 8 == 0 && hd <= 128 && hdp % 8 == 0 && ld % 8 == 0 && ((uintptr_t)qkv % 16) == 0 &&
         ((uintptr_t)Rh % 16) == 0 && ((uintptr_t)Rw % 16) == 0) {
         const int64_t nslices = (int64_t)B * H * (gh + gw);
         hipLaunchKernelGGL(relpos_bias_mma_kernel, dim3((unsigned)((nslices + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv, ld, T, H,
-                           hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nslices);
+                           hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nslices, in_rows, (const __bf16*)pad_row);
         MARS_LAUNCH_CHECK();
         return 0;
     }
+    MARS_CHECK(!in_rows, "relpos_bias_rows: a row map needs bf16 queries, grids and tables up to 16 a side, head dims a multiple of 8 up to 128");
     const size_t shm = (size_t)(nmax + kmax) * (hd + 1) * sizeof(float);
     MARS_CHECK(shm <= 64 * 1024 && (int64_t)B * H <= 65535, "relpos_bias: grid side %d, table side %d or head dim %d too large", nmax, kmax, hd);
     dim3 grid((unsigned)nmax, (unsigned)(B * H), 2), block(256);
@@ -899,6 +906,11 @@ extern "C" int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, in
     else hipLaunchKernelGGL(relpos_bias_kernel<float>, grid, block, shm, (hipStream_t)stream, (const float*)qkv, ld, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w);
     MARS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int marship_relpos_bias(const void* qkv, int64_t ld, int B, int T, int H, int hd, int hdp, int gw, int Hk, int Wk,
+                                   const float* Rh, const float* Rw, float* rel_h, float* rel_w, int dtype, void* stream) {
+    return marship_relpos_bias_rows(qkv, ld, B, T, H, hd, hdp, gw, Hk, Wk, Rh, Rw, rel_h, rel_w, nullptr, nullptr, dtype, stream);
 }
 
 extern "C" int marship_softmax_bias_rows(const float* S, int64_t lds_, void* P, int64_t ldp, int64_t nrows, int T, const float* rel_h,

@@ -372,7 +372,6 @@ static int layernorm_launch(const float* x, int64_t x_stride, const float* w, co
         else if (nch <= 6) { MARS_LN(6) } else { MARS_LN(8) }
 #undef MARS_LN
     } else {
-        MARS_CHECK(!out_rows, "layernorm_rows: rows and pointers must be 16-byte aligned, D a multiple of 4");
         if (out_dtype == 1) hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps);
         else hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
     }
@@ -383,12 +382,6 @@ static int layernorm_launch(const float* x, int64_t x_stride, const float* w, co
 extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
                                  int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream) {
     return layernorm_launch(x, x_stride, w, b, y, y_stride, rows, D, eps, nullptr, out_dtype, stream);
-}
-
-extern "C" int marship_layernorm_rows(const float* x, int64_t x_stride, const float* w, const float* b, void* y, int64_t y_stride, int rows,
-                                      int D, float eps, const int32_t* out_rows, int out_dtype, void* stream) {
-    MARS_CHECK(out_rows, "layernorm_rows: null row map");
-    return layernorm_launch(x, x_stride, w, b, y, y_stride, rows, D, eps, out_rows, out_dtype, stream);
 }
 
 extern "C" int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, float* watch,

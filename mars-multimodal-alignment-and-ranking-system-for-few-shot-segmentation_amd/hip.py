@@ -48,7 +48,6 @@ _SIGNATURES = {
     "marship_set_gemm_slots": [_I],
     "marship_gemm_split_rows": [_P],
     "marship_layernorm": [_P, _L, _P, _P, _P, _L, _I, _I, _F, _I, _P],
-    "marship_layernorm_rows": [_P, _L, _P, _P, _P, _L, _I, _I, _F, _P, _I, _P],
     "marship_ln_finish": [_P, _I, _I, _I, _F, _P, _P, _F, _P],
     "marship_row_stats": [_P, _L, _I, _I, _F, _P, _P, _L, _P, _P, _F, _P],
     "marship_im2col": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _I, _P],
@@ -83,8 +82,9 @@ _SIGNATURES = {
     "marship_points_in_masks": [_P, _I, _I, _I, _P, _I, _P, _P],
     "marship_gather_rows": [_P, _L, _I, _P, _P, _L, _I, _L, _I, _I, _P],
     "marship_relpos_bias": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "marship_relpos_bias_rows": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "marship_sam_attn": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
-    "marship_sam_attn_rows": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P],
+    "marship_sam_attn_rows": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "marship_softmax_bias_rows": [_P, _L, _P, _L, _L, _I, _P, _P, _I, _I, _I, _P],
     "marship_fourier_pe": [_P, _P, _I, _P, _P, _P, _L, _L, _P],
     "marship_add_cast": [_P, _P, _L, _P, _L, _I, _I, _P],

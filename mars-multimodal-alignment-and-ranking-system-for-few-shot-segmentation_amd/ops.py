@@ -239,23 +239,14 @@ def row_stats(x: torch.Tensor, eps: float, hi: torch.Tensor, lo: torch.Tensor, s
                                           stream()), "marship_row_stats")
 
 
-def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float, out_rows: Optional[torch.Tensor] = None):
-    """out[r] = LayerNorm(x[r]); with ``out_rows`` (i32 on the device, one entry a row of x, the caller's own map: every entry
-    negative or a row of ``out``): out[out_rows[r]] = LayerNorm(x[r]), rows of ``out`` that no entry names are left alone."""
-    _dev(x, w, b, out, out_rows)
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float):
+    _dev(x, w, b, out)
     _req(x.dtype == torch.float32 and x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1, "layernorm: bad x/out")
     rows, D = x.shape
-    _req(out.shape[1] == D and w.numel() == D and b.numel() == D, "layernorm: shape mismatch")
-    _req((rows - 1) * x.stride(0) + D <= _avail(x), "layernorm: overrun")
-    if out_rows is None:
-        _req(out.shape[0] == rows and (rows - 1) * out.stride(0) + D <= _avail(out), "layernorm: overrun")
-        hip.check(hip.lib().marship_layernorm(ptr(x), x.stride(0), ptr(w), ptr(b), ptr(out), out.stride(0), rows, D, eps,
-                                              dt(out), stream()), "marship_layernorm")
-        return
-    _req(out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() >= rows, "layernorm: out_rows must be i32, one entry a row")
-    _req((out.shape[0] - 1) * out.stride(0) + D <= _avail(out), "layernorm: overrun")
-    hip.check(hip.lib().marship_layernorm_rows(ptr(x), x.stride(0), ptr(w), ptr(b), ptr(out), out.stride(0), rows, D, eps, ptr(out_rows),
-                                               dt(out), stream()), "marship_layernorm_rows")
+    _req(out.shape[0] == rows and out.shape[1] == D and w.numel() == D and b.numel() == D, "layernorm: shape mismatch")
+    _req((rows - 1) * x.stride(0) + D <= _avail(x) and (rows - 1) * out.stride(0) + D <= _avail(out), "layernorm: overrun")
+    hip.check(hip.lib().marship_layernorm(ptr(x), x.stride(0), ptr(w), ptr(b), ptr(out), out.stride(0), rows, D, eps,
+                                          dt(out), stream()), "marship_layernorm")
 
 
 def im2col(img: torch.Tensor, p: int, out: torch.Tensor, *, mean=None, std=None, prescale: float = 1.0, col_off: int = 0):
@@ -637,36 +628,54 @@ def attn_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
                                            B, H, hd, Tq, Tk, scale, int(q_shared) | 2 * int(kv_shared), dt(q), stream()), "marship_attn_small")
 
 
+def _row_map(what: str, in_rows, pad_row, n: int, width: int):
+    _req((in_rows is None) == (pad_row is None), what + ": in_rows and pad_row come together")
+    if in_rows is not None:
+        _req(in_rows.dtype == torch.int32 and in_rows.is_contiguous() and in_rows.numel() >= n, what + ": in_rows must be i32, one entry a token row")
+        _req(pad_row.dtype == torch.bfloat16 and pad_row.is_contiguous() and pad_row.numel() >= width, what + ": pad_row must be one bf16 row of qkv")
+
+
 def relpos_bias(qkv: torch.Tensor, B: int, T: int, H: int, hd: int, hdp: int, gw: int, Rh: torch.Tensor, Rw: torch.Tensor,
-                rel_h: torch.Tensor, rel_w: torch.Tensor):
-    _dev(qkv, Rh, Rw, rel_h, rel_w)
-    _req(qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape[0] >= B * T, "relpos_bias: qkv")
+                rel_h: torch.Tensor, rel_w: torch.Tensor, in_rows: Optional[torch.Tensor] = None, pad_row: Optional[torch.Tensor] = None):
+    """Decomposed relative-position terms of B images (windows) of T tokens.  With ``in_rows`` (i32 on the device, the caller's own
+    map: every entry negative or a row of ``qkv``) token row r is row in_rows[r] of qkv, or ``pad_row`` for a negative entry."""
+    _dev(qkv, Rh, Rw, rel_h, rel_w, in_rows, pad_row)
+    _req(qkv.dim() == 2 and qkv.stride(1) == 1 and (in_rows is not None or qkv.shape[0] >= B * T), "relpos_bias: qkv")
     _req(Rh.dtype == torch.float32 and Rw.dtype == torch.float32 and Rh.is_contiguous() and Rw.is_contiguous(), "relpos_bias: tables")
     gh = T // gw
     Hk, Wk = Rh.shape[1], Rw.shape[1]
     _req(tuple(Rh.shape) == (gh, Hk, hd) and tuple(Rw.shape) == (gw, Wk, hd), "relpos_bias: table shapes")
     _req(rel_h.dtype == torch.float32 and rel_w.dtype == torch.float32 and rel_h.numel() >= B * H * T * Hk and rel_w.numel() >= B * H * T * Wk,
          "relpos_bias: outputs")
+    _row_map("relpos_bias", in_rows, pad_row, B * T, 3 * H * hdp)
+    if in_rows is not None:
+        hip.check(hip.lib().marship_relpos_bias_rows(ptr(qkv), qkv.stride(0), B, T, H, hd, hdp, gw, Hk, Wk, ptr(Rh), ptr(Rw), ptr(rel_h), ptr(rel_w),
+                                                     ptr(in_rows), ptr(pad_row), dt(qkv), stream()), "marship_relpos_bias_rows")
+        return
     hip.check(hip.lib().marship_relpos_bias(ptr(qkv), qkv.stride(0), B, T, H, hd, hdp, gw, Hk, Wk, ptr(Rh), ptr(Rw), ptr(rel_h), ptr(rel_w),
                                             dt(qkv), stream()), "marship_relpos_bias")
 
 
 def sam_attn(qkv: torch.Tensor, out: torch.Tensor, rel_h: torch.Tensor, rel_w: torch.Tensor, nb: int, T: int, H: int, hdp: int,
-             Hk: int, Wk: int, scale: float, out_rows: Optional[torch.Tensor] = None):
-    """out[nb*T, H*hdp] = attention of packed bf16 qkv rows with the decomposed relative-position bias, fused.  With ``out_rows``
-    (i32 on the device, one entry a token row, the caller's own map: every entry negative or a row of ``out``) the result of
-    token row r goes to out[out_rows[r]], or nowhere for a negative entry."""
-    _dev(qkv, out, rel_h, rel_w, out_rows)
+             Hk: int, Wk: int, scale: float, in_rows: Optional[torch.Tensor] = None, pad_row: Optional[torch.Tensor] = None,
+             out_rows: Optional[torch.Tensor] = None):
+    """out[nb*T, H*hdp] = attention of packed bf16 qkv rows with the decomposed relative-position bias, fused.  Row maps (i32 on
+    the device, one entry a token row, the caller's own: every entry negative or a row of ``qkv`` / ``out``): token row r is row
+    in_rows[r] of qkv, or ``pad_row`` (one row laid out like a row of qkv) for a negative entry; its result goes to
+    out[out_rows[r]], or nowhere for a negative entry."""
+    _dev(qkv, out, rel_h, rel_w, in_rows, pad_row, out_rows)
     _req(qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and qkv.dim() == 2 and out.dim() == 2, "sam_attn: bf16 rows")
-    _req(qkv.stride(1) == 1 and out.stride(1) == 1 and qkv.shape[0] >= nb * T and (out_rows is not None or out.shape[0] >= nb * T), "sam_attn: rows")
+    _req(qkv.stride(1) == 1 and out.stride(1) == 1 and (in_rows is not None or qkv.shape[0] >= nb * T)
+         and (out_rows is not None or out.shape[0] >= nb * T), "sam_attn: rows")
     _req(out_rows is None or (out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() >= nb * T),
          "sam_attn: out_rows must be i32, one entry a token row")
+    _row_map("sam_attn", in_rows, pad_row, nb * T, 3 * H * hdp)
     _req(qkv.shape[1] >= 3 * H * hdp and out.shape[1] >= H * hdp, "sam_attn: columns")
     _req(rel_h.dtype == torch.float32 and rel_w.dtype == torch.float32 and rel_h.numel() >= nb * H * T * Hk and rel_w.numel() >= nb * H * T * Wk,
          "sam_attn: bias terms")
-    if out_rows is not None:
+    if in_rows is not None or out_rows is not None:
         hip.check(hip.lib().marship_sam_attn_rows(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(rel_h), ptr(rel_w), nb, T, H, hdp, Hk, Wk,
-                                                  scale, ptr(out_rows), stream()), "marship_sam_attn_rows")
+                                                  scale, ptr(in_rows), ptr(pad_row), ptr(out_rows), stream()), "marship_sam_attn_rows")
         return
     hip.check(hip.lib().marship_sam_attn(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(rel_h), ptr(rel_w), nb, T, H, hdp, Hk, Wk,
                                          scale, stream()), "marship_sam_attn")

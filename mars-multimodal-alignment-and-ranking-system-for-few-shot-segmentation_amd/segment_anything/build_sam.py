@@ -35,4 +35,5 @@ build_sam = build_sam_vit_h
 sam_model_registry = {"default": build_sam_vit_h, "vit_h": build_sam_vit_h, "vit_l": build_sam_vit_l, "vit_b": build_sam_vit_b,
                       "tiny": lambda checkpoint=None, **kw: _build("tiny", checkpoint, **kw),
                       "tiny80": lambda checkpoint=None, **kw: _build("tiny80", checkpoint, **kw),
-                      "geom": lambda checkpoint=None, **kw: _build("geom", checkpoint, **kw)}
+                      "geom": lambda checkpoint=None, **kw: _build("geom", checkpoint, **kw),
+                      "win14": lambda checkpoint=None, **kw: _build("win14", checkpoint, **kw)}

@@ -138,6 +138,9 @@ class ImageEncoderViT:
             parts = [_pad_heads_rows(wq[s * D:(s + 1) * D], bq[s * D:(s + 1) * D], H, hd, hdp) for s in range(3)]
             b.qkv = Lin(torch.cat([w for w, _ in parts]), torch.cat([bb for _, bb in parts]), dtype, dev)
             b.proj = Lin(_pad_heads_cols(sd[p + ".attn.proj.weight"], H, hd, hdp), sd[p + ".attn.proj.bias"], dtype, dev)
+            # a window's padding token as the projection leaves it: the bias, rounded as its output is (what the row-map kernels
+            # need: bf16 queries, windows of 65 to 224 tokens, head dims a multiple of 8 up to 128)
+            b.qkv_pad = b.qkv.b.to(torch.bfloat16) if (dtype == torch.bfloat16 and 64 < b.ws * b.ws <= 224 and hd % 8 == 0 and hd <= 128) else None
             size = G if b.ws == 0 else b.ws
             b.Rh = _dev_f32(_rel_table(size, sd[p + ".attn.rel_pos_h"]), dev)
             b.Rw = _dev_f32(_rel_table(size, sd[p + ".attn.rel_pos_w"]), dev)
@@ -203,36 +206,37 @@ class ImageEncoderViT:
         ops.linear(w["a0"], self.patch.w, w["X"], bias=self.patch.b, residual=self.pos)       # patch embed + pos embed
         X = w["X"]
         for b in self.blocks:
-            # (fused_partition: norm1 writes the rows of the windows and the attention the rows of the image; the windows'
-            # padding rows of xw are never written and stay the zeros they were made as)
-            fp = self.fused_partition and b.ws > 0 and self.fused_attention
-            if fp:
-                ops.layernorm(X, b.ln1[0], b.ln1[1], w["xw"], 1e-6, out_rows=self.unpart_idx)
-            else:
-                ops.layernorm(X, b.ln1[0], b.ln1[1], w["xn"], 1e-6)
+            # fused_partition: the windows are not materialised.  The projection runs on the image's rows; the relative-position
+            # kernel and the attention read a window's tokens through the row map of window_partition (a padding token is
+            # what the projection makes of a zero row: its bias) and the attention writes in image order.
+            fp = self.fused_partition and b.ws > 0 and self.fused_attention and b.qkv_pad is not None
+            ops.layernorm(X, b.ln1[0], b.ln1[1], w["xn"], 1e-6)
             if b.ws > 0:
                 if not fp:
                     ops.gather_rows(w["xn"], self.part_idx, w["xw"])                             # zero rows for the padding
-                src, nb, Tt, gw = w["xw"], self.n_win, b.ws * b.ws, b.ws
+                src, nb, Tt, gw = (w["xn"] if fp else w["xw"]), self.n_win, b.ws * b.ws, b.ws
             else:
                 src, nb, Tt, gw = w["xn"], 1, T, G
-            rows = nb * Tt
+            rows = T if fp else nb * Tt
             qkv = w["qkv"][:rows]
             ops.linear(src[:rows], b.qkv.w, qkv, bias=b.qkv.b)
             rel_h = self._rel_buf("h", nb * H * Tt * (Tt // gw))
             rel_w = self._rel_buf("w", nb * H * Tt * gw)
-            ops.relpos_bias(qkv, nb, Tt, H, hd, hdp, gw, b.Rh, b.Rw, rel_h, rel_w)
             ao = w["ao"][:rows]
             if fp:
+                ops.relpos_bias(qkv, nb, Tt, H, hd, hdp, gw, b.Rh, b.Rw, rel_h, rel_w, in_rows=self.part_idx, pad_row=b.qkv_pad)
                 ao = w["aou"]
-                ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5, out_rows=self.part_idx)
-            elif self.fused_attention:
-                ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5)
+                ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5, in_rows=self.part_idx, pad_row=b.qkv_pad,
+                             out_rows=self.part_idx)
             else:
-                if hdp % 64:
-                    raise RuntimeError("this tower stores its heads unpadded for the fused attention kernel; build it with MARS_FLASH=0 "
-                                       "(or MARS_SAM_HEAD80=0) to run the three-launch form")
-                self._attn.run(qkv, 0, qkv, H * hdp, qkv, 2 * H * hdp, ao, nb, H, Tt, Tt, hdp, hd ** -0.5, rel=(rel_h, rel_w, Tt // gw, gw))
+                ops.relpos_bias(qkv, nb, Tt, H, hd, hdp, gw, b.Rh, b.Rw, rel_h, rel_w)
+                if self.fused_attention:
+                    ops.sam_attn(qkv, ao, rel_h, rel_w, nb, Tt, H, hdp, Tt // gw, gw, hd ** -0.5)
+                else:
+                    if hdp % 64:
+                        raise RuntimeError("this tower stores its heads unpadded for the fused attention kernel; build it with MARS_FLASH=0 "
+                                           "(or MARS_SAM_HEAD80=0) to run the three-launch form")
+                    self._attn.run(qkv, 0, qkv, H * hdp, qkv, 2 * H * hdp, ao, nb, H, Tt, Tt, hdp, hd ** -0.5, rel=(rel_h, rel_w, Tt // gw, gw))
             if b.ws > 0 and not fp:
                 ops.gather_rows(ao, self.unpart_idx, w["aou"])
                 ao = w["aou"]

@@ -245,6 +245,8 @@ SAM_ARCHS = {
     "tiny80": SamCfg(320, 2, 4, (1,), img_size=96, window_size=4, out_chans=64, dec_heads=4, dec_mlp_dim=96, iou_head_hidden=48),
     # the real geometry (1024 px, 64 x 64 tokens, 14 x 14 windows padded to 70, 256 decoder channels) on a narrow, shallow tower
     "geom": SamCfg(128, 2, 2, (1,), dec_mlp_dim=256),
+    # 14 x 14 windows (the shipped window) on a 20 x 20 token grid: padded border windows at the size the windows' kernels take
+    "win14": SamCfg(320, 2, 4, (1,), img_size=320, window_size=14, out_chans=64, dec_heads=4, dec_mlp_dim=96, iou_head_hidden=48),
 }
 
 

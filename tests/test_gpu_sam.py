@@ -399,13 +399,14 @@ def test_fused_attention_with_relpos_bias(pkg, nb, gh, gw, H, hd, hdp):
         assert float(out.view(nb * T, H, hdp)[..., hd:].abs().max()) == 0.0
 
 
-def test_row_maps_of_layernorm_and_attention_equal_the_gathers(pkg):
-    """norm1 writing the rows of the windows and the attention writing the rows of the image (row maps inside the two
-    kernels) == the same kernels followed by gather_rows, bit for bit; rows that no entry names keep their contents."""
+def test_row_maps_of_relpos_and_attention_equal_materialised_windows(pkg):
+    """The relative-position terms and the attention of windows read through the row map of window_partition (padding
+    tokens = one row of padding values) and written back in image order == the same kernels on materialised windows
+    followed by gather_rows, bit for bit; rows of the output that no entry names keep their contents."""
     ops = pkg.ops
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(12)
-    G, ws, D = 20, 14, 160
+    G, ws, H, hd = 20, 14, 2, 80
     nw = -(-G // ws)
     part = torch.full((nw * nw * ws * ws,), -1, dtype=torch.int32)
     unpart = torch.zeros(G * G, dtype=torch.int32)
@@ -419,43 +420,49 @@ def test_row_maps_of_layernorm_and_attention_equal_the_gathers(pkg):
                         part[r] = y * G + x
                         unpart[y * G + x] = r
     part, unpart = part.to(dev), unpart.to(dev)
-    X = torch.randn(G * G, D, generator=g).to(dev)
-    w, b = torch.randn(D, generator=g).to(dev), torch.randn(D, generator=g).to(dev)
-    xn = torch.empty(G * G, D, dtype=torch.bfloat16, device=dev)
-    ops.layernorm(X, w, b, xn, 1e-6)
-    want = torch.empty(part.numel(), D, dtype=torch.bfloat16, device=dev)
-    ops.gather_rows(xn, part, want)
-    got = torch.zeros_like(want)
-    ops.layernorm(X, w, b, got, 1e-6, out_rows=unpart)
-    assert torch.equal(got, want)
-    # attention of the windows, written back in image order
-    H, hd = 2, 80
     T, nb = ws * ws, nw * nw
-    qkv = (torch.randn(nb * T, 3 * H * hd, generator=g)).to(torch.bfloat16).to(dev)
-    rel_h = (torch.randn(nb * H, T, ws, generator=g)).to(dev)
-    rel_w = (torch.randn(nb * H, T, ws, generator=g)).to(dev)
+    img = torch.randn(G * G, 3 * H * hd, generator=g).to(torch.bfloat16).to(dev)          # qkv of the image's rows
+    pad = torch.randn(3 * H * hd, generator=g).to(torch.bfloat16).to(dev)
+    win = torch.empty(nb * T, 3 * H * hd, dtype=torch.bfloat16, device=dev)              # the windows, materialised
+    ops.gather_rows(img, part, win)
+    win[part < 0] = pad
+    Rh, Rw = torch.randn(ws, ws, hd, generator=g).to(dev), torch.randn(ws, ws, hd, generator=g).to(dev)
+    rel = [[torch.empty(nb * H * T, ws, device=dev) for _ in range(2)] for _ in range(2)]
+    ops.relpos_bias(win, nb, T, H, hd, hd, ws, Rh, Rw, rel[0][0], rel[0][1])
+    ops.relpos_bias(img, nb, T, H, hd, hd, ws, Rh, Rw, rel[1][0], rel[1][1], in_rows=part, pad_row=pad)
+    assert torch.equal(rel[0][0], rel[1][0]) and torch.equal(rel[0][1], rel[1][1])
     ao = torch.empty(nb * T, H * hd, dtype=torch.bfloat16, device=dev)
-    ops.sam_attn(qkv, ao, rel_h, rel_w, nb, T, H, hd, ws, ws, hd ** -0.5)
+    ops.sam_attn(win, ao, rel[0][0], rel[0][1], nb, T, H, hd, ws, ws, hd ** -0.5)
     want = torch.empty(G * G, H * hd, dtype=torch.bfloat16, device=dev)
     ops.gather_rows(ao, unpart, want)
     got = torch.full_like(want, 7.0)
-    ops.sam_attn(qkv, got, rel_h, rel_w, nb, T, H, hd, ws, ws, hd ** -0.5, out_rows=part)
+    ops.sam_attn(img, got, rel[0][0], rel[0][1], nb, T, H, hd, ws, ws, hd ** -0.5, in_rows=part, pad_row=pad, out_rows=part)
     assert torch.equal(got, want)
+    only_out = torch.full_like(want, 7.0)
+    ops.sam_attn(win, only_out, rel[0][0], rel[0][1], nb, T, H, hd, ws, ws, hd ** -0.5, out_rows=part)
+    assert torch.equal(only_out, want)
 
 
-def test_encoder_with_row_maps_equals_the_gathers(pkg, monkeypatch):
+def test_encoder_without_materialised_windows_equals_the_gathers(pkg, monkeypatch):
+    """14 x 14 windows on a 20 x 20 token grid (border windows padded): the encoder that reads the windows through row
+    maps == the encoder that gathers them, bit for bit, on two images through the same work buffers."""
     sa = pkg.segment_anything
-    sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["tiny80"], seed=5)
-    img = GOLD["sam_tiny80_image"]
+    sd = pkg.synth.sam_state_dict(pkg.synth.SAM_ARCHS["win14"], seed=5)
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, size=(200, 320, 3), dtype=np.uint8), rng.integers(0, 256, size=(320, 240, 3), dtype=np.uint8)]
     feats = []
     for flag in ("1", "0"):
         monkeypatch.setenv("MARS_SAM_FUSED_PARTITION", flag)
-        sam = sa.sam_model_registry["tiny80"](state_dict=sd, device="cuda", dtype=torch.bfloat16)
+        sam = sa.sam_model_registry["win14"](state_dict=sd, device="cuda", dtype=torch.bfloat16)
+        assert (sam.image_encoder.blocks[0].qkv_pad is not None) and sam.image_encoder.fused_partition == (flag == "1")
         pred = sa.SamPredictor(sam)
-        pred.set_image(img)
-        pred.set_image(img)                                  # (a second image through the same work buffers)
-        feats.append(pred.features.float().clone())
-    assert torch.equal(feats[0], feats[1])
+        out = []
+        for img in imgs:
+            pred.set_image(img)
+            out.append(pred.features.float().clone())
+        feats.append(out)
+    assert torch.equal(feats[0][0], feats[1][0]) and torch.equal(feats[0][1], feats[1][1])
+    assert not torch.equal(feats[0][0], feats[0][1])
 
 
 @pytest.mark.parametrize("arch", ["tiny", "tiny80"])
