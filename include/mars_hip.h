@@ -81,8 +81,10 @@ int marship_set_gemm_variant(int variant);
 int marship_gemm_variant_for(const MarsGemm* g);
 /* Tuning hook (no reference counterpart): under "chosen by shape" a tall unbatched product whose tiles would
  * leave most CUs idle in their last round runs as two launches, rows [0, r) on the large tile and rows [r, M)
- * as a product of their own.  marship_set_gemm_split(0) keeps every product in one launch; returns the
- * previous setting.  marship_gemm_split_rows returns r (M when the product is not split). */
+ * as a product of their own; a bf16 product of between one and two rounds of 256 x 256 tiles whose row tiles fit
+ * one round is cut the other way: whole columns of tiles that fill one round, then the remaining columns.
+ * marship_set_gemm_split(0) keeps every product in one launch; returns the
+ * previous setting.  marship_gemm_split_rows returns r (M when the product is not split by rows). */
 int marship_set_gemm_split(int on);
 int marship_gemm_split_rows(const MarsGemm* g);
 /* Tuning hook (no reference counterpart): the number of workgroups a persistent launch (variant 12: every

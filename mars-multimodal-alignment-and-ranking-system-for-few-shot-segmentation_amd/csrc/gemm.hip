@@ -256,6 +256,22 @@ static int split_rows(const MarsGemm* g, int v) {
     return (int)(row_tiles * 256);
 }
 
+// Columns the first of two launches covers, or N when the product is not cut by columns.  A bf16 product of between one and
+// two rounds of 256 x 256 tiles whose row tiles fit a round (the fc1 of a ViT-H layer on 4096 tokens: 16 x 20 tiles
+// = 1.25 rounds) goes out as whole columns of tiles that fill one round on the 256 x 256 pair-fill shape (16 x 16) and
+// the remaining columns as a product of their own (80 -> 68 us); whatever the policy would pick for the whole
+// product leaves a quarter of a second round to a few CUs.
+static int split_cols(const MarsGemm* g) {
+    if (!g_gemm_split.load(std::memory_order_relaxed) || g_gemm_variant.load(std::memory_order_relaxed) != 4) return g->N;
+    if (g->in_dtype != 1 || g->nb0 * g->nb1 != 1 || g->ln_copy || g->ln_lo || g->ln_part || g->ln_stat || g->ln_colsum) return g->N;
+    const int slots = cu_count();
+    const int64_t ntm = (g->M + 255) / 256, ntn = (g->N + 255) / 256, tiles = ntm * ntn;
+    if (g->K < 1024 || tiles <= slots || tiles >= 2 * (int64_t)slots || ntm > slots) return g->N;
+    const int64_t cols = slots / ntm;                    // whole columns of tiles in one round
+    if (cols < 1 || cols >= ntn || cols * ntm * 4 < (int64_t)slots * 3) return g->N;
+    return (int)(cols * 256);
+}
+
 extern "C" int marship_gemm_variant_for(const MarsGemm* g) {
     MARS_CHECK(g && g->M > 0 && g->N > 0 && g->nb0 > 0 && g->nb1 > 0, "gemm_variant_for: bad shape");
     return pick_variant(g);
@@ -304,10 +320,29 @@ extern "C" int marship_gemm(const MarsGemm* g, void* stream) {
         }
     }
     if (g_gemm_variant.load(std::memory_order_relaxed) != 0) {
-        const int v = pick_variant(g);
-        const int rows = split_rows(g, v);
         const int forced = g_gemm_slots.load(std::memory_order_relaxed);
         const int slots = forced > 0 ? forced : cu_count();
+        const int cols = split_cols(g);
+        if (cols < g->N) {
+            // columns [0, cols) are one round of 256 x 256 tiles; the rest is a product of its own
+            MarsGemm head = *g, tail = *g;
+            head.N = cols;
+            tail.N = g->N - cols;
+            tail.B = (const char*)g->B + (int64_t)cols * g->ldb * es;
+            tail.C = (char*)g->C + (int64_t)cols * (g->out_dtype == 1 ? 2 : 4);
+            if (g->bias) tail.bias = g->bias + cols;
+            if (g->gamma) tail.gamma = g->gamma + cols;
+            if (g->residual) tail.residual = g->residual + cols;
+            mars_gemm_ring_launch(head, s, 8 - 4, slots);
+            MARS_LAUNCH_CHECK();
+            const int vt = pick_variant(&tail);
+            if (vt == 3 || vt >= 5) mars_gemm_ring_launch(tail, s, vt == 3 ? 0 : vt - 4, slots);
+            else mars_gemm_glds_launch(tail, s, vt);
+            MARS_LAUNCH_CHECK();
+            return 0;
+        }
+        const int v = pick_variant(g);
+        const int rows = split_rows(g, v);
         if (rows < g->M) {
             // rows [0, rows) fill whole rounds of tiles; the rest is a product of its own
             MarsGemm head = *g, tail = *g;

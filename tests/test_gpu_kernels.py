@@ -233,6 +233,32 @@ def test_gemm_split_launch(pkg, cuda):
     assert torch.equal(x1[:rows], x2[:rows])
 
 
+def test_gemm_column_split(pkg, cuda):
+    """A product of 1.25 rounds of 256 x 256 tiles (16 x 20: the fc1 of a ViT-H layer on 4096 tokens) goes out as one round
+    of whole tile columns and the remaining columns as a launch of their own: equal to the product kept in one launch up to
+    the summation order of another tile shape, and to f32 on the same operands, with bias, GELU and bf16 output or residual."""
+    lib = pkg.hip.lib()
+    M, N, K = 4096, 5120, 1024
+    a = _rand((M, K), 51, cuda).to(torch.bfloat16)
+    b = (_rand((N, K), 52, cuda) * 0.05).to(torch.bfloat16)
+    bias = _rand((N,), 53, cuda)
+    ref = a.float() @ b.float().t() + bias
+    for act, odt in ((1, torch.bfloat16), (0, torch.float32)):
+        outs = []
+        for split in (1, 0):
+            old = lib.marship_set_gemm_split(split)
+            try:
+                out = torch.full((M, N), float("nan"), device=cuda, dtype=odt) if act else _rand((M, N), 54, cuda)
+                pkg.ops.linear(a, b, out, bias=bias, act=act, residual=None if act else out)
+            finally:
+                lib.marship_set_gemm_split(old)
+            outs.append(out.float())
+        want = torch.nn.functional.gelu(ref) if act else ref + _rand((M, N), 54, cuda)
+        tol = (5e-3 if act else 1e-3) * want.abs().clamp(min=1.0)        # (bf16 output: half a unit in the last place)
+        assert bool(((outs[0] - want).abs() <= tol).all()) and bool(((outs[1] - want).abs() <= tol).all())
+        assert bool(((outs[0] - outs[1]).abs() <= 2 * tol).all())
+
+
 @pytest.mark.parametrize("M,D,N2,K2", [(1000, 128, 384, 512), (4616, 1024, 4096, 1024), (36928, 1024, 3072, 4096)])
 def test_gemm_folded_layernorm(pkg, cuda, M, D, N2, K2):
     """A LayerNorm between two products, folded into both: the product that writes the f32 stream leaves its
