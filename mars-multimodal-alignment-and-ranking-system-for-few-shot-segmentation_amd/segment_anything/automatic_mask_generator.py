@@ -115,7 +115,7 @@ class SamAutomaticMaskGenerator:
         keep_lists["iou"].append(iou_h[idx])
         keep_lists["stab"].append(stab[idx])
         keep_lists["boxes"].append(st[idx, 2:6].float())
-        keep_lists["points"].extend(points[int(i) // nm] for i in idx.tolist())      # rows repeat once per output mask
+        keep_lists["points"].append((points, (idx // nm).numpy()))                   # rows repeat once per output mask; resolved for what the NMS keeps
         if defer and masks is None:
             keep_lists["planes"] = idx
             keep_lists["deferred"] = (low, plan)
@@ -214,7 +214,10 @@ class SamAutomaticMaskGenerator:
             ops.resample_threshold(low, pk.to(torch.int32).to(dev), *plan, self.predictor.model.mask_threshold, out["masks"])
             pkd = pk.to(dev)
             out["low"] = low[pkd // low.shape[1], pkd % low.shape[1]]
-        out["points"] = [[[x + x0, y + y0] for x, y in points[i]] for i in keep.tolist()]
+        # the prompt points of the kept masks: entry i of the concatenated survivors lives in chunk c at i - starts[c]
+        starts = np.cumsum([0] + [len(rows) for _, rows in points])
+        chunk = np.searchsorted(starts, keep.numpy(), side="right") - 1
+        out["points"] = [[[x + x0, y + y0] for x, y in points[c][0][int(points[c][1][i - starts[c]])]] for i, c in zip(keep.tolist(), chunk.tolist())]
         out["boxes"] = out["boxes"] + torch.tensor([[x0, y0, x0, y0]], dtype=out["boxes"].dtype)
         if (ch, cw) != (oh, ow):                                                      # masks of a crop, zero outside it
             full = torch.zeros(out["masks"].shape[0], oh, ow, dtype=out["masks"].dtype, device=out["masks"].device)
