@@ -52,13 +52,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <typename TOUT, int NCH>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int64_t xs,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            TOUT* __restrict__ y, int64_t ys, int rows, int D, float eps,
-                                                            const int32_t* __restrict__ out_rows) {
+                                                            TOUT* __restrict__ y, int64_t ys, int rows, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const int64_t orow = out_rows ? out_rows[row] : row;          // (a negative entry: the row is not written)
-    if (orow < 0) return;
     const f32x4* xr = (const f32x4*)(x + (int64_t)row * xs);
     const int nc = D >> 2;                 // chunks per row
     f32x4 v[NCH];                          // NCH = ceil(D / 256) chunks per lane
@@ -79,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-    TOUT* yr = y + orow * ys;
+    TOUT* yr = y + (int64_t)row * ys;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = i * 64 + lane;
@@ -90,6 +87,36 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
             else { bf16x4 ob; ob[0] = (__bf16)o[0]; ob[1] = (__bf16)o[1]; ob[2] = (__bf16)o[2]; ob[3] = (__bf16)o[3]; ((bf16x4*)yr)[c] = ob; }
         }
     }
+}
+
+// The same for launches of a few thousand rows, which the row-per-wave form leaves latency bound (four waves a SIMD, each
+// a chain of load - sum - squares - sum - store: 13.5 us for 4096 x 1280): a workgroup per row, one or two 16-byte chunks a
+// thread, statistics through LDS.  Four times the waves in flight for the same bytes.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void layernorm_row_wg_kernel(const float* __restrict__ x, int64_t xs, const float* __restrict__ w,
+                                                               const float* __restrict__ b, TOUT* __restrict__ y, int64_t ys, int D, float eps) {
+    __shared__ float sm[8];
+    const int64_t row = blockIdx.x;
+    const f32x4* xr = (const f32x4*)(x + row * xs);
+    const int nc = D >> 2, c0 = threadIdx.x, c1 = threadIdx.x + 256;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v0 = c0 < nc ? xr[c0] : zero, v1 = c1 < nc ? xr[c1] : zero;
+    f32x4 w0 = zero, w1 = zero, b0 = zero, b1 = zero;
+    if (c0 < nc) { w0 = ((const f32x4*)w)[c0]; b0 = ((const f32x4*)b)[c0]; }
+    if (c1 < nc) { w1 = ((const f32x4*)w)[c1]; b1 = ((const f32x4*)b)[c1]; }
+    const float mean = block_reduce_sum(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3])), sm) / (float)D;
+    float q = 0.f;
+    if (c0 < nc) { v0 -= mean; q += (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]); }
+    if (c1 < nc) { v1 -= mean; q += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]); }
+    const float rstd = 1.0f / sqrtf(block_reduce_sum(q, sm) / (float)D + eps);
+    TOUT* yr = y + row * ys;
+    auto put = [&](int c, const f32x4& v, const f32x4& wv, const f32x4& bv) {
+        const f32x4 o = v * rstd * wv + bv;
+        if constexpr (sizeof(TOUT) == 4) ((f32x4*)yr)[c] = o;
+        else { bf16x4 ob; ob[0] = (__bf16)o[0]; ob[1] = (__bf16)o[1]; ob[2] = (__bf16)o[2]; ob[3] = (__bf16)o[3]; ((bf16x4*)yr)[c] = ob; }
+    };
+    if (c0 < nc) put(c0, v0, w0, b0);
+    if (c1 < nc) put(c1, v1, w1, b1);
 }
 
 // ---------------------------------------------------------------- LayerNorm folded into the products around it
@@ -355,19 +382,25 @@ inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
 
 }  // namespace
 
-static int layernorm_launch(const float* x, int64_t x_stride, const float* w, const float* b, void* y, int64_t y_stride, int rows, int D,
-                            float eps, const int32_t* out_rows, int out_dtype, void* stream) {
+extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
+                                 int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream) {
     MARS_CHECK(x && w && b && y, "layernorm: null pointer");
     MARS_CHECK(rows > 0 && D > 0 && D <= 2048, "layernorm: D=%d out of range (1..2048)", D);
     dim3 grid((rows + 3) / 4), block(256);
     const int ysz = out_dtype == 1 ? 2 : 4;
     const bool vec = D % 4 == 0 && x_stride % 4 == 0 && y_stride % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
                      (uintptr_t)b % 16 == 0 && (uintptr_t)y % (4 * ysz) == 0;
+    if (vec && rows <= 8192 && D >= 512 && D <= 2048) {
+        if (out_dtype == 1) hipLaunchKernelGGL(layernorm_row_wg_kernel<__bf16>, dim3(rows), block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, D, eps);
+        else hipLaunchKernelGGL(layernorm_row_wg_kernel<float>, dim3(rows), block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, D, eps);
+        MARS_LAUNCH_CHECK();
+        return 0;
+    }
     if (vec) {
         const int nch = (D / 4 + 63) / 64;
 #define MARS_LN(N)                                                                                                         \
-        if (out_dtype == 1) hipLaunchKernelGGL((layernorm_vec_kernel<__bf16, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps, out_rows); \
-        else hipLaunchKernelGGL((layernorm_vec_kernel<float, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps, out_rows);
+        if (out_dtype == 1) hipLaunchKernelGGL((layernorm_vec_kernel<__bf16, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, rows, D, eps); \
+        else hipLaunchKernelGGL((layernorm_vec_kernel<float, N>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, rows, D, eps);
         if (nch <= 1) { MARS_LN(1) } else if (nch == 2) { MARS_LN(2) } else if (nch == 3) { MARS_LN(3) } else if (nch == 4) { MARS_LN(4) }
         else if (nch <= 6) { MARS_LN(6) } else { MARS_LN(8) }
 #undef MARS_LN
@@ -377,11 +410,6 @@ static int layernorm_launch(const float* x, int64_t x_stride, const float* w, co
     }
     MARS_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* w, const float* b, void* y,
-                                 int64_t y_stride, int rows, int D, float eps, int out_dtype, void* stream) {
-    return layernorm_launch(x, x_stride, w, b, y, y_stride, rows, D, eps, nullptr, out_dtype, stream);
 }
 
 extern "C" int marship_ln_finish(const float* part, int nparts, int rows, int D, float eps, float* stat, float* watch,
