@@ -2,6 +2,7 @@
 // transposes, row softmax, attention-map averaging, SwiGLU gate, casts, row L2 norm.
 // One wave per row wherever a row fits the 64 lanes' registers; 16-byte vector access
 // on the contiguous axis where the layout allows it.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/mars_hip.h"
 
@@ -390,7 +391,9 @@ extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* 
     const int ysz = out_dtype == 1 ? 2 : 4;
     const bool vec = D % 4 == 0 && x_stride % 4 == 0 && y_stride % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
                      (uintptr_t)b % 16 == 0 && (uintptr_t)y % (4 * ysz) == 0;
-    if (vec && rows <= 8192 && D >= 512 && D <= 2048) {
+    // (MARS_LN_ROW_WG=0, read once: the row-per-wave form for every launch)
+    static const bool row_wg = [] { const char* e = getenv("MARS_LN_ROW_WG"); return !(e && e[0] == '0'); }();
+    if (row_wg && vec && rows <= 8192 && D >= 512 && D <= 2048) {
         if (out_dtype == 1) hipLaunchKernelGGL(layernorm_row_wg_kernel<__bf16>, dim3(rows), block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, D, eps);
         else hipLaunchKernelGGL(layernorm_row_wg_kernel<float>, dim3(rows), block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, D, eps);
         MARS_LAUNCH_CHECK();
