@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     }
 }
 
-// The same for launches of a few thousand rows, which the row-per-wave form leaves latency bound (four waves a SIMD, each
-// a chain of load - sum - squares - sum - store: 13.5 us for 4096 x 1280): a workgroup per row, one or two 16-byte chunks a
-// thread, statistics through LDS.  Four times the waves in flight for the same bytes.
+// A workgroup per row, one or two 16-byte chunks a thread, statistics through LDS (rows of 512 to 2048 values, bf16
+// outputs).  The row-per-wave form leaves launches of a few thousand rows latency bound - four waves a SIMD, each a chain
+// of load - sum - squares - sum - store: 13.5 us for 4096 x 1280 - and this one has four times the waves in flight for
+// the same bytes; at 36928 x 1024 the two take the same time.
 template <typename TOUT>
 __global__ __launch_bounds__(256) void layernorm_row_wg_kernel(const float* __restrict__ x, int64_t xs, const float* __restrict__ w,
                                                                const float* __restrict__ b, TOUT* __restrict__ y, int64_t ys, int D, float eps) {
@@ -392,10 +393,12 @@ extern "C" int marship_layernorm(const float* x, int64_t x_stride, const float* 
     const bool vec = D % 4 == 0 && x_stride % 4 == 0 && y_stride % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 &&
                      (uintptr_t)b % 16 == 0 && (uintptr_t)y % (4 * ysz) == 0;
     // (MARS_LN_ROW_WG=0, read once: the row-per-wave form for every launch)
+    // The form is chosen by the output type and the width alone, never by the number of rows: the two forms add a row's
+    // statistics in different orders, and a row must give the same bits whatever batch it is part of.  f32 outputs (the
+    // f32 towers) keep the row-per-wave form their comparisons with the f32 oracle were made with.
     static const bool row_wg = [] { const char* e = getenv("MARS_LN_ROW_WG"); return !(e && e[0] == '0'); }();
-    if (row_wg && vec && rows <= 8192 && D >= 512 && D <= 2048) {
-        if (out_dtype == 1) hipLaunchKernelGGL(layernorm_row_wg_kernel<__bf16>, dim3(rows), block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, D, eps);
-        else hipLaunchKernelGGL(layernorm_row_wg_kernel<float>, dim3(rows), block, 0, (hipStream_t)stream, x, x_stride, w, b, (float*)y, y_stride, D, eps);
+    if (row_wg && vec && out_dtype == 1 && D >= 512 && D <= 2048) {
+        hipLaunchKernelGGL(layernorm_row_wg_kernel<__bf16>, dim3(rows), block, 0, (hipStream_t)stream, x, x_stride, w, b, (__bf16*)y, y_stride, D, eps);
         MARS_LAUNCH_CHECK();
         return 0;
     }

@@ -233,6 +233,23 @@ def test_gemm_split_launch(pkg, cuda):
     assert torch.equal(x1[:rows], x2[:rows])
 
 
+@pytest.mark.parametrize("D", [384, 512, 768, 1024, 1280, 1536, 2048])
+def test_layernorm_does_not_depend_on_the_number_of_rows(pkg, cuda, D):
+    """The LayerNorm form (a workgroup or a wave per row) is chosen by width and output type alone: a row gives the same
+    bits in a small launch and inside a large one, and matches torch."""
+    ops = pkg.ops
+    x = _rand((9000, D), 71, cuda) * 3 + 0.5
+    w, b = _rand((D,), 72, cuda), _rand((D,), 73, cuda)
+    for odt in (torch.float32, torch.bfloat16):
+        big = torch.empty(9000, D, device=cuda, dtype=odt)
+        ops.layernorm(x, w, b, big, 1e-6)
+        small = torch.empty(3000, D, device=cuda, dtype=odt)
+        ops.layernorm(x[:3000], w, b, small, 1e-6)
+        assert torch.equal(small, big[:3000])
+        ref = torch.nn.functional.layer_norm(x[:3000], (D,), w, b, 1e-6)
+        assert float((small.float() - ref).abs().max()) < (1e-5 if odt == torch.float32 else 0.05)
+
+
 def test_gemm_column_split(pkg, cuda):
     """A product of 1.25 rounds of 256 x 256 tiles (16 x 20: the fc1 of a ViT-H layer on 4096 tokens) goes out as one round
     of whole tile columns and the remaining columns as a launch of their own: equal to the product kept in one launch up to
