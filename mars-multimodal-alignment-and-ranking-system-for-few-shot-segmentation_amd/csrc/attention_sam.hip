@@ -326,8 +326,11 @@ __global__ __launch_bounds__(NW * 64, (ALLKV && HD <= 80) ? 4 : 2) void sam_attn
             const int myq = q0 + qb * 16 + r16;
             if (myq < T) {
                 const float inv = 1.0f / o[qb][DM][0];
-                const int64_t orow = (ROWMAP && out_rows) ? out_rows[(int64_t)b * T + myq] : (int64_t)b * T + myq;      // (negative: not written)
-                if (orow < 0) continue;
+                int64_t orow = (int64_t)b * T + myq;
+                if constexpr (ROWMAP) {
+                    if (out_rows) orow = out_rows[orow];        // (negative: not written)
+                    if (orow < 0) continue;
+                }
                 __bf16* op = O + orow * ldo + h * HD;
 #pragma unroll
                 for (int m = 0; m < DM; ++m) {
